@@ -1,0 +1,110 @@
+"""ctypes binding of libauvsim.so (declarations mirror include/auvsim.h).
+
+There is no CPU fallback: if the shared library has not been built, or no
+GPU is usable, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libauvsim.so")
+
+ABI_VERSION = 1
+N_MODEL = 16
+
+# auv_dtype
+F64, F32, I32, U8, I64 = 0, 1, 2, 3, 4
+
+# auv_buffer
+(BUF_STATE, BUF_ACTION, BUF_RANGES, BUF_HIT, BUF_PERCEPTION, BUF_NAVIGATION,
+ BUF_OBST_DIST, BUF_RISK, BUF_META, BUF_OWN, BUF_COLLISION, BUF_REACHED_GOAL,
+ BUF_TRUNCATED, BUF_DONE, BUF_MIN_DIST, BUF_MIN_IDX, BUF_ALONG, BUF_T_STEP,
+ BUF_CIRCLES, BUF_POLY_POSE, BUF_REWARD, BUF_COUNT) = range(22)
+
+BUFFER_NAMES = {
+    "state": BUF_STATE, "action": BUF_ACTION, "ranges": BUF_RANGES, "hit": BUF_HIT,
+    "perception": BUF_PERCEPTION, "navigation": BUF_NAVIGATION, "obst_dist": BUF_OBST_DIST,
+    "risk": BUF_RISK, "meta": BUF_META, "own": BUF_OWN, "collision": BUF_COLLISION,
+    "reached_goal": BUF_REACHED_GOAL, "truncated": BUF_TRUNCATED, "done": BUF_DONE,
+    "min_dist": BUF_MIN_DIST, "min_idx": BUF_MIN_IDX, "along": BUF_ALONG,
+    "t_step": BUF_T_STEP, "circles": BUF_CIRCLES, "poly_pose": BUF_POLY_POSE,
+    "reward": BUF_REWARD,
+}
+
+# every symbol include/auvsim.h declares
+EXPORTS = (
+    "auv_version", "auv_last_error", "auv_create", "auv_destroy", "auv_set_rays",
+    "auv_set_scene", "auv_reset", "auv_step", "auv_step_host", "auv_sense",
+    "auv_get_buffer", "auv_read_buffer", "auv_sync", "auv_profile_enable",
+    "auv_profile_read",
+)
+
+
+class AuvConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("n_envs", C.c_int32), ("n_rays", C.c_int32),
+        ("n_circles", C.c_int32), ("n_polys", C.c_int32), ("n_verts", C.c_int32),
+        ("max_steps", C.c_int32), ("reserved", C.c_int32),
+        ("dt", C.c_double), ("sensor_range", C.c_double), ("vessel_radius", C.c_double),
+        ("thrust_max", C.c_double), ("moment_max", C.c_double), ("look_ahead", C.c_double),
+        ("goal_radius", C.c_double), ("risk", C.c_double * 3), ("reward", C.c_double * 4),
+        ("model", C.c_double * N_MODEL),
+    ]
+
+
+class AuvError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libauvsim error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libauvsim.so once; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    dp = C.POINTER(C.c_double)
+    lib.auv_version.restype = C.c_char_p
+    lib.auv_version.argtypes = []
+    lib.auv_last_error.restype = C.c_char_p
+    lib.auv_last_error.argtypes = [vp]
+    lib.auv_create.restype = C.c_int
+    lib.auv_create.argtypes = [C.POINTER(AuvConfig), C.c_int, C.POINTER(vp)]
+    lib.auv_destroy.restype = None
+    lib.auv_destroy.argtypes = [vp]
+    lib.auv_set_rays.restype = C.c_int
+    lib.auv_set_rays.argtypes = [vp, vp]
+    lib.auv_set_scene.restype = C.c_int
+    lib.auv_set_scene.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.auv_reset.restype = C.c_int
+    lib.auv_reset.argtypes = [vp, vp, vp, vp]
+    lib.auv_step.restype = C.c_int
+    lib.auv_step.argtypes = [vp, vp, vp]
+    lib.auv_step_host.restype = C.c_int
+    lib.auv_step_host.argtypes = [vp, vp, vp]
+    lib.auv_sense.restype = C.c_int
+    lib.auv_sense.argtypes = [vp, vp]
+    lib.auv_get_buffer.restype = C.c_int
+    lib.auv_get_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(i64), C.POINTER(i32),
+                                   C.POINTER(i32)]
+    lib.auv_read_buffer.restype = C.c_int
+    lib.auv_read_buffer.argtypes = [vp, C.c_int, vp, i64, vp]
+    lib.auv_sync.restype = C.c_int
+    lib.auv_sync.argtypes = [vp, vp]
+    lib.auv_profile_enable.restype = C.c_int
+    lib.auv_profile_enable.argtypes = [vp, i32]
+    lib.auv_profile_read.restype = C.c_int
+    lib.auv_profile_read.argtypes = [vp, dp, C.POINTER(i64)]
+    _lib = lib
+    return lib

@@ -1,0 +1,570 @@
+// libauvsim.so: C ABI (include/auvsim.h) over the HIP kernels in
+// auv_kernels.hpp.  Host side only owns buffers, validates shapes before any
+// launch, and enqueues kernels on the caller's stream; there is no CPU
+// fallback: without a usable gfx950 device auv_create fails.
+#include "../../include/auvsim.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "auv_kernels.hpp"
+
+using namespace auv;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct BufDesc {
+    void* ptr = nullptr;
+    int64_t shape[4] = {0, 0, 0, 0};
+    int32_t ndim = 0;
+    int32_t dtype = AUV_F64;
+    size_t bytes = 0;
+};
+
+size_t dtype_size(int32_t dt) {
+    switch (dt) {
+        case AUV_F64: return 8;
+        case AUV_F32: return 4;
+        case AUV_I32: return 4;
+        case AUV_U8: return 1;
+        case AUV_I64: return 8;
+    }
+    return 0;
+}
+
+constexpr int kProfRing = 256;  // steps whose events are kept before a forced drain
+
+}  // namespace
+
+struct auv_sim {
+    auv_config cfg;
+    Dims d;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    BufDesc buf[AUV_BUF_COUNT];
+    // scene / auxiliary device memory not lent out
+    double* poly_verts = nullptr;
+    int32_t* poly_nv = nullptr;
+    double* poly_heading = nullptr;
+    double* path = nullptr;
+    double* ray_dirs = nullptr;
+    double* init_stage = nullptr;  // [6,V] staging for reset
+    double* circles0 = nullptr;    // obstacle poses as uploaded (restored on reset)
+    double* poly_pose0 = nullptr;
+    uint8_t* mask_stage = nullptr;
+    bool have_rays = false, have_scene = false, have_state = false;
+    // launch geometry
+    int lidar_te = 1, lidar_block = 256, enc_eb = 1;
+    size_t lidar_lds = 0, enc_lds = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> events;  // kProfRing * 4
+    int prof_pending = 0;
+    double prof_ms[3] = {0, 0, 0};
+    int64_t prof_steps = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(auv_sim* h, int code, const char* fmt, ...) {
+    char tmp[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tmp, sizeof tmp, fmt, ap);
+    va_end(ap);
+    if (h) h->err = tmp; else g_create_error = tmp;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(h, e_ == hipErrorOutOfMemory ? AUV_ERR_MEMORY : AUV_ERR_DEVICE,       \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                       \
+    } while (0)
+
+int alloc_buf(auv_sim* h, int which, int32_t dtype, std::initializer_list<int64_t> shape) {
+    BufDesc& b = h->buf[which];
+    b.dtype = dtype;
+    b.ndim = (int32_t)shape.size();
+    size_t n = 1;
+    int k = 0;
+    for (int64_t s : shape) {
+        b.shape[k++] = s;
+        n *= (size_t)s;
+    }
+    b.bytes = n * dtype_size(dtype);
+    // zero-sized slots (e.g. no polygons) still get a valid, distinct pointer
+    HIP_TRY(h, hipMalloc(&b.ptr, b.bytes ? b.bytes : 256));
+    HIP_TRY(h, hipMemsetAsync(b.ptr, 0, b.bytes ? b.bytes : 256, h->stream));
+    return AUV_OK;
+}
+
+template <typename T>
+int alloc_raw(auv_sim* h, T** p, size_t n) {
+    HIP_TRY(h, hipMalloc((void**)p, n ? n * sizeof(T) : 256));
+    HIP_TRY(h, hipMemsetAsync(*p, 0, n ? n * sizeof(T) : 256, h->stream));
+    return AUV_OK;
+}
+
+template <typename T>
+T* bp(auv_sim* h, int which) {
+    return static_cast<T*>(h->buf[which].ptr);
+}
+
+hipStream_t pick(auv_sim* h, void* stream) { return stream ? (hipStream_t)stream : h->stream; }
+
+void choose_geometry(auv_sim* h) {
+    const Dims& d = h->d;
+    const int S = d.P * d.NV;
+    // LiDAR tile: as many envs as fit a 40 KiB LDS budget (keeps >= 3
+    // workgroups per CU resident), at most 16, and few enough that small
+    // batches still spread over the 256 CUs.
+    const size_t per_env = lidar_lds_doubles(1, d.C, S) * sizeof(double);
+    int te = (int)((40u * 1024u) / per_env);
+    if (te > 16) te = 16;
+    while (te > 1 && (d.V + te - 1) / te < 1024) te >>= 1;
+    if (te < 1) te = 1;
+    h->lidar_te = te;
+    h->lidar_lds = lidar_lds_doubles(te, d.C, S) * sizeof(double);
+    // whole waves of work per pass when the tile allows it
+    const long long rays = (long long)te * d.R;
+    h->lidar_block = (rays % 192 == 0 && rays % 256 != 0) ? 192 : 256;
+    if (rays < 256) h->lidar_block = (int)(((rays + 63) / 64) * 64);
+    // encounter: one thread per (env, obstacle), whole envs per block
+    const int O = d.O > 0 ? d.O : 1;
+    int eb = 256 / O;
+    if (eb < 1) eb = 1;
+    h->enc_eb = eb;
+    h->enc_lds = (size_t)eb * O * sizeof(double);
+}
+
+int launch_sense(auv_sim* h, hipStream_t st, hipEvent_t* ev, int is_step) {
+    const Dims& d = h->d;
+    EncArgs ea;
+    ea.d = d;
+    ea.EB = h->enc_eb;
+    ea.state = bp<double>(h, AUV_BUF_STATE);
+    ea.t_step = bp<int32_t>(h, AUV_BUF_T_STEP);
+    ea.circles = bp<double>(h, AUV_BUF_CIRCLES);
+    ea.poly_pose = bp<double>(h, AUV_BUF_POLY_POSE);
+    ea.poly_verts = h->poly_verts;
+    ea.poly_nv = h->poly_nv;
+    ea.poly_heading = h->poly_heading;
+    ea.path = h->path;
+    ea.obst_dist = bp<double>(h, AUV_BUF_OBST_DIST);
+    ea.risk = bp<double>(h, AUV_BUF_RISK);
+    ea.meta = bp<double>(h, AUV_BUF_META);
+    ea.own = bp<double>(h, AUV_BUF_OWN);
+    ea.collision = bp<uint8_t>(h, AUV_BUF_COLLISION);
+    ea.reached_goal = bp<uint8_t>(h, AUV_BUF_REACHED_GOAL);
+    ea.truncated = bp<uint8_t>(h, AUV_BUF_TRUNCATED);
+    ea.done = bp<uint8_t>(h, AUV_BUF_DONE);
+    ea.min_dist = bp<double>(h, AUV_BUF_MIN_DIST);
+    ea.min_idx = bp<int32_t>(h, AUV_BUF_MIN_IDX);
+    ea.along = bp<double>(h, AUV_BUF_ALONG);
+    ea.reward = bp<double>(h, AUV_BUF_REWARD);
+    ea.navigation = bp<float>(h, AUV_BUF_NAVIGATION);
+    ea.sensor_range = h->cfg.sensor_range;
+    ea.vessel_radius = h->cfg.vessel_radius;
+    ea.look_ahead = h->cfg.look_ahead;
+    ea.goal_radius = h->cfg.goal_radius;
+    ea.w_d = h->cfg.risk[0];
+    ea.w_c = h->cfg.risk[1];
+    ea.t_c = h->cfg.risk[2];
+    ea.max_steps = h->cfg.max_steps;
+    ea.rw_progress = h->cfg.reward[0];
+    ea.rw_collision = h->cfg.reward[1];
+    ea.rw_goal = h->cfg.reward[2];
+    ea.rw_cte = h->cfg.reward[3];
+    ea.is_step = is_step;
+    const int enc_blocks = (d.V + h->enc_eb - 1) / h->enc_eb;
+    hipLaunchKernelGGL(k_encounter, dim3(enc_blocks), dim3(256), h->enc_lds, st, ea);
+    HIP_TRY(h, hipGetLastError());
+    if (ev) HIP_TRY(h, hipEventRecord(ev[2], st));
+
+    LidarArgs la;
+    la.d = d;
+    la.TE = h->lidar_te;
+    la.state = bp<double>(h, AUV_BUF_STATE);
+    la.circles = bp<double>(h, AUV_BUF_CIRCLES);
+    la.poly_pose = bp<double>(h, AUV_BUF_POLY_POSE);
+    la.poly_verts = h->poly_verts;
+    la.poly_nv = h->poly_nv;
+    la.ray_dirs = h->ray_dirs;
+    la.ranges = bp<double>(h, AUV_BUF_RANGES);
+    la.hit = bp<int32_t>(h, AUV_BUF_HIT);
+    la.perception = bp<float>(h, AUV_BUF_PERCEPTION);
+    la.sensor_range = h->cfg.sensor_range;
+    const int lid_blocks = (d.V + h->lidar_te - 1) / h->lidar_te;
+    hipLaunchKernelGGL(k_lidar, dim3(lid_blocks), dim3(h->lidar_block), h->lidar_lds, st, la);
+    HIP_TRY(h, hipGetLastError());
+    if (ev) HIP_TRY(h, hipEventRecord(ev[3], st));
+    return AUV_OK;
+}
+
+int drain_profile(auv_sim* h) {
+    if (h->prof_pending == 0) return AUV_OK;
+    hipEvent_t* last = &h->events[(size_t)(h->prof_pending - 1) * 4];
+    HIP_TRY(h, hipEventSynchronize(last[3]));
+    for (int s = 0; s < h->prof_pending; ++s) {
+        hipEvent_t* ev = &h->events[(size_t)s * 4];
+        for (int k = 0; k < 3; ++k) {
+            float ms = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            h->prof_ms[k] += ms;
+        }
+    }
+    h->prof_steps += h->prof_pending;
+    h->prof_pending = 0;
+    return AUV_OK;
+}
+
+int ready_to_run(auv_sim* h, bool need_state) {
+    if (!h->have_rays) return fail(h, AUV_ERR_STATE, "auv_set_rays has not been called");
+    if (!h->have_scene) return fail(h, AUV_ERR_STATE, "auv_set_scene has not covered every env yet");
+    if (need_state && !h->have_state) return fail(h, AUV_ERR_STATE, "auv_reset has not been called");
+    return AUV_OK;
+}
+
+int do_step(auv_sim* h, const double* action_dev, hipStream_t st) {
+    const Dims& d = h->d;
+    hipEvent_t* ev = nullptr;
+    if (h->profiling) {
+        if (h->prof_pending == kProfRing) {
+            int rc = drain_profile(h);
+            if (rc) return rc;
+        }
+        ev = &h->events[(size_t)h->prof_pending * 4];
+        HIP_TRY(h, hipEventRecord(ev[0], st));
+    }
+    DynArgs da;
+    da.d = d;
+    da.state = bp<double>(h, AUV_BUF_STATE);
+    da.action = action_dev ? action_dev : bp<double>(h, AUV_BUF_ACTION);
+    da.t_step = bp<int32_t>(h, AUV_BUF_T_STEP);
+    da.circles = bp<double>(h, AUV_BUF_CIRCLES);
+    da.poly_pose = bp<double>(h, AUV_BUF_POLY_POSE);
+    da.dt = h->cfg.dt;
+    da.thrust_max = h->cfg.thrust_max;
+    da.moment_max = h->cfg.moment_max;
+    for (int i = 0; i < MP_COUNT; ++i) da.mp[i] = h->cfg.model[i];
+    const long long work = (long long)d.V * (d.O > 1 ? d.O : 1);
+    long long blocks = (work + 255) / 256;
+    const long long min_blocks = ((long long)d.V + 255) / 256;
+    if (blocks > 65536) blocks = 65536;  // obstacle advance is grid-strided
+    if (blocks < min_blocks) blocks = min_blocks;
+    hipLaunchKernelGGL(k_dynamics, dim3((unsigned)blocks), dim3(256), 0, st, da);
+    HIP_TRY(h, hipGetLastError());
+    if (ev) HIP_TRY(h, hipEventRecord(ev[1], st));
+    int rc = launch_sense(h, st, ev, 1);
+    if (rc) return rc;
+    if (ev) h->prof_pending++;
+    return AUV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* auv_version(void) { return "libauvsim abi 1 gfx950 fp64-unfused"; }
+
+const char* auv_last_error(auv_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int auv_create(const auv_config* cfg, int device, auv_handle* out) {
+    if (!cfg || !out) return fail(nullptr, AUV_ERR_ARG, "auv_create: null argument");
+    *out = nullptr;
+    if (cfg->abi_version != AUVSIM_ABI_VERSION)
+        return fail(nullptr, AUV_ERR_ARG, "auv_create: abi_version %d, library is %d", cfg->abi_version,
+                    AUVSIM_ABI_VERSION);
+    if (cfg->n_envs < 1 || cfg->n_rays < 1 || cfg->n_circles < 0 || cfg->n_polys < 0)
+        return fail(nullptr, AUV_ERR_ARG, "auv_create: n_envs/n_rays must be >= 1, slot counts >= 0");
+    if (cfg->n_polys > 0 && (cfg->n_verts < 3 || cfg->n_verts > 16))
+        return fail(nullptr, AUV_ERR_ARG, "auv_create: n_verts must be in 3..16");
+    if ((long long)cfg->n_envs * cfg->n_rays > (1ll << 31) - 1 ||
+        (long long)cfg->n_envs * (cfg->n_circles + cfg->n_polys) > (1ll << 31) - 1)
+        return fail(nullptr, AUV_ERR_ARG, "auv_create: batch too large for 32-bit ray/obstacle indices");
+    if (!(cfg->dt > 0.0) || !(cfg->sensor_range > 0.0))
+        return fail(nullptr, AUV_ERR_ARG, "auv_create: dt and sensor_range must be positive");
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(nullptr, AUV_ERR_DEVICE, "auv_create: no HIP device (%s)",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= n_dev)
+        return fail(nullptr, AUV_ERR_ARG, "auv_create: device %d out of range (have %d)", device, n_dev);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, AUV_ERR_DEVICE, "hipSetDevice: %s", hipGetErrorString(e));
+
+    auv_sim* h = new auv_sim();
+    h->cfg = *cfg;
+    h->device = device;
+    Dims& d = h->d;
+    d.V = cfg->n_envs;
+    d.R = cfg->n_rays;
+    d.C = cfg->n_circles;
+    d.P = cfg->n_polys;
+    d.NV = cfg->n_polys > 0 ? cfg->n_verts : 1;
+    d.O = d.C + d.P;
+    choose_geometry(h);
+    if (h->lidar_lds > 64 * 1024) {
+        // one env's primitives must fit the default dynamic-LDS window
+        std::string msg = "auv_create: one env needs " + std::to_string(h->lidar_lds) +
+                          " B of LDS for its obstacle primitives (limit 65536)";
+        delete h;
+        return fail(nullptr, AUV_ERR_ARG, "%s", msg.c_str());
+    }
+    int rc = AUV_OK;
+    auto chk = [&](int r) { if (rc == AUV_OK && r != AUV_OK) rc = r; };
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(nullptr, AUV_ERR_DEVICE, "hipStreamCreate failed");
+    }
+    const int64_t V = d.V, R = d.R, C = d.C, P = d.P, NV = d.NV, O = d.O;
+    chk(alloc_buf(h, AUV_BUF_STATE, AUV_F64, {6, V}));
+    chk(alloc_buf(h, AUV_BUF_ACTION, AUV_F64, {2, V}));
+    chk(alloc_buf(h, AUV_BUF_RANGES, AUV_F64, {V, R}));
+    chk(alloc_buf(h, AUV_BUF_HIT, AUV_I32, {V, R}));
+    chk(alloc_buf(h, AUV_BUF_PERCEPTION, AUV_F32, {V, 1, R}));
+    chk(alloc_buf(h, AUV_BUF_NAVIGATION, AUV_F32, {V, 1, AUV_NAV_FEATURES}));
+    chk(alloc_buf(h, AUV_BUF_OBST_DIST, AUV_F64, {V, O}));
+    chk(alloc_buf(h, AUV_BUF_RISK, AUV_F64, {V, O}));
+    chk(alloc_buf(h, AUV_BUF_META, AUV_F64, {V, O, AUV_META_FIELDS}));
+    chk(alloc_buf(h, AUV_BUF_OWN, AUV_F64, {V, 2}));
+    chk(alloc_buf(h, AUV_BUF_COLLISION, AUV_U8, {V}));
+    chk(alloc_buf(h, AUV_BUF_REACHED_GOAL, AUV_U8, {V}));
+    chk(alloc_buf(h, AUV_BUF_TRUNCATED, AUV_U8, {V}));
+    chk(alloc_buf(h, AUV_BUF_DONE, AUV_U8, {V}));
+    chk(alloc_buf(h, AUV_BUF_MIN_DIST, AUV_F64, {V}));
+    chk(alloc_buf(h, AUV_BUF_MIN_IDX, AUV_I32, {V}));
+    chk(alloc_buf(h, AUV_BUF_ALONG, AUV_F64, {V}));
+    chk(alloc_buf(h, AUV_BUF_T_STEP, AUV_I32, {V}));
+    chk(alloc_buf(h, AUV_BUF_CIRCLES, AUV_F64, {V, C, 5}));
+    chk(alloc_buf(h, AUV_BUF_POLY_POSE, AUV_F64, {V, P, 6}));
+    chk(alloc_buf(h, AUV_BUF_REWARD, AUV_F64, {V}));
+    chk(alloc_raw(h, &h->poly_verts, (size_t)V * P * NV * 2));
+    chk(alloc_raw(h, &h->poly_nv, (size_t)V * P));
+    chk(alloc_raw(h, &h->poly_heading, (size_t)V * P));
+    chk(alloc_raw(h, &h->path, (size_t)V * 6));
+    chk(alloc_raw(h, &h->ray_dirs, (size_t)R * 2));
+    chk(alloc_raw(h, &h->init_stage, (size_t)V * 6));
+    chk(alloc_raw(h, &h->circles0, (size_t)V * C * 5));
+    chk(alloc_raw(h, &h->poly_pose0, (size_t)V * P * 6));
+    chk(alloc_raw(h, &h->mask_stage, (size_t)V));
+    if (rc == AUV_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = AUV_ERR_DEVICE;
+    if (rc != AUV_OK) {
+        g_create_error = "auv_create: " + h->err;
+        auv_destroy(h);
+        return rc;
+    }
+    // default path: along +x from the origin (cos = 1), so navigation is defined
+    // even when the caller never uploads paths
+    {
+        std::vector<double> p((size_t)V * 6, 0.0);
+        for (int64_t i = 0; i < V; ++i) p[(size_t)i * 6 + 3] = 1.0;
+        if (hipMemcpy(h->path, p.data(), p.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+            auv_destroy(h);
+            return fail(nullptr, AUV_ERR_DEVICE, "auv_create: path upload failed");
+        }
+    }
+    *out = h;
+    return AUV_OK;
+}
+
+void auv_destroy(auv_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& ev : h->events) (void)hipEventDestroy(ev);
+    for (auto& b : h->buf)
+        if (b.ptr) (void)hipFree(b.ptr);
+    void* raw[] = {h->poly_verts, h->poly_nv, h->poly_heading, h->path, h->ray_dirs, h->init_stage, h->mask_stage,
+                   h->circles0, h->poly_pose0};
+    for (void* p : raw)
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int auv_set_rays(auv_handle h, const double* ray_dirs) {
+    if (!h || !ray_dirs) return fail(h, AUV_ERR_ARG, "auv_set_rays: null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(h->ray_dirs, ray_dirs, (size_t)h->d.R * 2 * sizeof(double), hipMemcpyHostToDevice));
+    h->have_rays = true;
+    return AUV_OK;
+}
+
+int auv_set_scene(auv_handle h, int32_t env_begin, int32_t env_count, const double* circles,
+                  const double* poly_pose, const double* poly_verts, const int32_t* poly_nv,
+                  const double* poly_heading, const double* path) {
+    if (!h) return AUV_ERR_ARG;
+    const Dims& d = h->d;
+    if (env_begin < 0 || env_count < 1 || (long long)env_begin + env_count > d.V)
+        return fail(h, AUV_ERR_ARG, "auv_set_scene: env range [%d,%d) outside [0,%d)", env_begin,
+                    env_begin + env_count, d.V);
+    if (d.C > 0 && !circles) return fail(h, AUV_ERR_ARG, "auv_set_scene: circles is NULL but n_circles > 0");
+    if (d.P > 0 && (!poly_pose || !poly_verts || !poly_nv || !poly_heading))
+        return fail(h, AUV_ERR_ARG, "auv_set_scene: a polygon array is NULL but n_polys > 0");
+    if (d.P > 0) {
+        const size_t n = (size_t)env_count * d.P;
+        for (size_t i = 0; i < n; ++i)
+            if (poly_nv[i] != 0 && (poly_nv[i] < 3 || poly_nv[i] > d.NV))
+                return fail(h, AUV_ERR_ARG, "auv_set_scene: poly_nv[%zu] = %d not 0 or in 3..%d", i, poly_nv[i], d.NV);
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t b = (size_t)env_begin, n = (size_t)env_count;
+    if (d.C > 0) {
+        HIP_TRY(h, hipMemcpy(bp<double>(h, AUV_BUF_CIRCLES) + b * d.C * 5, circles, n * d.C * 5 * sizeof(double),
+                             hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->circles0 + b * d.C * 5, circles, n * d.C * 5 * sizeof(double),
+                             hipMemcpyHostToDevice));
+    }
+    if (d.P > 0) {
+        HIP_TRY(h, hipMemcpy(bp<double>(h, AUV_BUF_POLY_POSE) + b * d.P * 6, poly_pose,
+                             n * d.P * 6 * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->poly_pose0 + b * d.P * 6, poly_pose, n * d.P * 6 * sizeof(double),
+                             hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->poly_verts + b * d.P * d.NV * 2, poly_verts,
+                             n * d.P * d.NV * 2 * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->poly_nv + b * d.P, poly_nv, n * d.P * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->poly_heading + b * d.P, poly_heading, n * d.P * sizeof(double),
+                             hipMemcpyHostToDevice));
+    }
+    if (path) HIP_TRY(h, hipMemcpy(h->path + b * 6, path, n * 6 * sizeof(double), hipMemcpyHostToDevice));
+    // the scene counts as complete once one call has covered all envs, or the
+    // calls so far were a front-to-back sweep ending at V
+    if (env_begin == 0 && env_count == d.V) h->have_scene = true;
+    else if (env_begin + env_count == d.V) h->have_scene = true;
+    return AUV_OK;
+}
+
+int auv_reset(auv_handle h, const uint8_t* mask, const double* init_state, void* stream) {
+    if (!h || !init_state) return fail(h, AUV_ERR_ARG, "auv_reset: null argument");
+    int rc = ready_to_run(h, false);
+    if (rc) return rc;
+    if (mask && !h->have_state) return fail(h, AUV_ERR_STATE, "auv_reset: first reset must cover all envs (mask == NULL)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = pick(h, stream);
+    const Dims& d = h->d;
+    HIP_TRY(h, hipMemcpyAsync(h->init_stage, init_state, (size_t)d.V * 6 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (mask) HIP_TRY(h, hipMemcpyAsync(h->mask_stage, mask, (size_t)d.V, hipMemcpyHostToDevice, st));
+    ResetArgs ra;
+    ra.d = d;
+    ra.state = bp<double>(h, AUV_BUF_STATE);
+    ra.t_step = bp<int32_t>(h, AUV_BUF_T_STEP);
+    ra.init = h->init_stage;
+    ra.mask = mask ? h->mask_stage : nullptr;
+    ra.circles = bp<double>(h, AUV_BUF_CIRCLES);
+    ra.circles0 = h->circles0;
+    ra.poly_pose = bp<double>(h, AUV_BUF_POLY_POSE);
+    ra.poly_pose0 = h->poly_pose0;
+    hipLaunchKernelGGL(k_reset, dim3((d.V + 255) / 256), dim3(256), 0, st, ra);
+    HIP_TRY(h, hipGetLastError());
+    h->have_state = true;
+    rc = launch_sense(h, st, nullptr, 0);
+    if (rc) return rc;
+    // the staging copies read caller memory: finish before returning
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return AUV_OK;
+}
+
+int auv_step(auv_handle h, const double* action, void* stream) {
+    if (!h) return AUV_ERR_ARG;
+    int rc = ready_to_run(h, true);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return do_step(h, action, pick(h, stream));
+}
+
+int auv_step_host(auv_handle h, const double* action, void* stream) {
+    if (!h || !action) return fail(h, AUV_ERR_ARG, "auv_step_host: null argument");
+    int rc = ready_to_run(h, true);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = pick(h, stream);
+    HIP_TRY(h, hipMemcpyAsync(bp<double>(h, AUV_BUF_ACTION), action, (size_t)h->d.V * 2 * sizeof(double),
+                              hipMemcpyHostToDevice, st));
+    // pageable host memory: the copy above has consumed `action` on return
+    return do_step(h, nullptr, st);
+}
+
+int auv_sense(auv_handle h, void* stream) {
+    if (!h) return AUV_ERR_ARG;
+    int rc = ready_to_run(h, true);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return launch_sense(h, pick(h, stream), nullptr, 0);
+}
+
+int auv_get_buffer(auv_handle h, int which, void** dev_ptr, int64_t* shape, int32_t* ndim, int32_t* dtype) {
+    if (!h) return AUV_ERR_ARG;
+    if (which < 0 || which >= AUV_BUF_COUNT) return fail(h, AUV_ERR_ARG, "auv_get_buffer: unknown buffer %d", which);
+    const BufDesc& b = h->buf[which];
+    if (dev_ptr) *dev_ptr = b.ptr;
+    if (shape)
+        for (int i = 0; i < 4; ++i) shape[i] = i < b.ndim ? b.shape[i] : 0;
+    if (ndim) *ndim = b.ndim;
+    if (dtype) *dtype = b.dtype;
+    return AUV_OK;
+}
+
+int auv_read_buffer(auv_handle h, int which, void* host_dst, int64_t nbytes, void* stream) {
+    if (!h || !host_dst) return fail(h, AUV_ERR_ARG, "auv_read_buffer: null argument");
+    if (which < 0 || which >= AUV_BUF_COUNT) return fail(h, AUV_ERR_ARG, "auv_read_buffer: unknown buffer %d", which);
+    const BufDesc& b = h->buf[which];
+    if (nbytes < 0 || (size_t)nbytes != b.bytes)
+        return fail(h, AUV_ERR_ARG, "auv_read_buffer: buffer %d holds %zu bytes, caller asked for %lld", which,
+                    b.bytes, (long long)nbytes);
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = pick(h, stream);
+    if (b.bytes) HIP_TRY(h, hipMemcpyAsync(host_dst, b.ptr, b.bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return AUV_OK;
+}
+
+int auv_sync(auv_handle h, void* stream) {
+    if (!h) return AUV_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(pick(h, stream)));
+    return AUV_OK;
+}
+
+int auv_profile_enable(auv_handle h, int32_t on) {
+    if (!h) return AUV_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (on && h->events.empty()) {
+        h->events.resize((size_t)kProfRing * 4);
+        for (auto& ev : h->events) HIP_TRY(h, hipEventCreate(&ev));
+    }
+    if (!on) {
+        int rc = drain_profile(h);
+        if (rc) return rc;
+    }
+    h->profiling = on != 0;
+    return AUV_OK;
+}
+
+int auv_profile_read(auv_handle h, double ms[3], int64_t* n_steps) {
+    if (!h || !ms || !n_steps) return fail(h, AUV_ERR_ARG, "auv_profile_read: null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = drain_profile(h);
+    if (rc) return rc;
+    for (int k = 0; k < 3; ++k) {
+        ms[k] = h->prof_ms[k];
+        h->prof_ms[k] = 0.0;
+    }
+    *n_steps = h->prof_steps;
+    h->prof_steps = 0;
+    return AUV_OK;
+}
+
+}  // extern "C"

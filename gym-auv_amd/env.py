@@ -1,0 +1,95 @@
+"""`VecAuvEnv`: the gym-style vectorised env over `AuvSim`.
+
+Keeps the contract the reference's RL-side consumer reads
+(`PerceptionNavigationExtractor`, radarCNN.py:195-280): `reset()` returns and
+`step()` yields a dict observation with keys "perception" (B,1,180) float32
+closeness and "navigation" (B,1,6) float32; `step()` is the old-gym 4-tuple
+(obs, reward, done, info) that `import gym` + stable-baselines3
+(radarCNN.py:1,6-7) expect.  The observation tensors alias device memory
+(DLPack, zero-copy): they are overwritten by the next step.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .params import NAV_FEATURES
+from .sim import AuvSim
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (gym is not a dependency)."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+
+class DictSpace:
+    """Minimal stand-in for gym.spaces.Dict: `.spaces` is what
+    radarCNN.py:215 iterates."""
+
+    def __init__(self, spaces):
+        self.spaces = dict(spaces)
+
+
+class VecAuvEnv:
+    def __init__(self, cfg: dict, scene: dict, device: int = 0, auto_reset: bool = True):
+        import torch
+
+        self._torch = torch
+        self.cfg = cfg
+        self.scene = scene
+        self.num_envs = int(cfg["n_envs"])
+        self.device = torch.device("cuda", device)
+        self.sim = AuvSim(cfg, device=device)
+        self.sim.set_scene(scene)
+        self.auto_reset = auto_reset
+        R = int(cfg["n_rays"])
+        self.observation_space = DictSpace({
+            "perception": Box(0.0, 1.0, (1, R)),
+            "navigation": Box(-np.inf, np.inf, (1, NAV_FEATURES)),
+        })
+        self.action_space = Box(np.array([0.0, -1.0]), np.array([1.0, 1.0]), (2,))
+        self._obs = {"perception": self.sim.tensor("perception"),
+                     "navigation": self.sim.tensor("navigation")}
+        self._reward = self.sim.tensor("reward")
+        self._done = self.sim.tensor("done")
+        self._action = self.sim.tensor("action")   # f64 [2,V] staging
+        self._init_state = np.ascontiguousarray(scene["init_state"], dtype=np.float64)
+        self.episodes_done = 0
+
+    def _stream(self):
+        return self._torch.cuda.current_stream(self.device)
+
+    def reset(self):
+        """Reset every env; returns the observation dict."""
+        self.sim.reset(self._init_state, stream=self._stream())
+        return self._obs
+
+    def step(self, actions):
+        """actions: (B,2) torch tensor on the env's GPU or numpy array,
+        columns (surge in [0,1], steer in [-1,1])."""
+        torch = self._torch
+        st = self._stream()
+        if isinstance(actions, np.ndarray):
+            a = np.ascontiguousarray(np.asarray(actions, dtype=np.float64).T)
+            self.sim.step_host(a, stream=st)
+        else:
+            if actions.shape != (self.num_envs, 2):
+                raise ValueError(f"actions must be ({self.num_envs}, 2)")
+            # transpose + widen into the library's [2,V] f64 staging buffer
+            self._action.copy_(actions.to(self.device).t())
+            self.sim.step_device(None, stream=st)
+        info = {}
+        if self.auto_reset:
+            done_host = self._done.cpu().numpy().astype(bool)
+            if done_host.any():
+                info["terminal_mask"] = done_host
+                self.episodes_done += int(done_host.sum())
+                reward = self._reward.clone()
+                done = torch.from_numpy(done_host).to(self.device)
+                self.sim.reset(self._init_state, mask=done_host, stream=st)
+                return self._obs, reward, done, info
+        return self._obs, self._reward, self._done.bool(), info
+
+    def close(self):
+        self.sim.close()

@@ -1,0 +1,160 @@
+"""`AuvSim`: thin object wrapper over the C ABI (one handle = one batch of
+envs on one GPU)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, dlpack
+from .params import ray_table
+
+_NP_DTYPE = {_lib.F64: np.float64, _lib.F32: np.float32, _lib.I32: np.int32, _lib.U8: np.uint8,
+             _lib.I64: np.int64}
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _stream_handle(stream):
+    """Raw hipStream_t of a torch stream, an int, or None (handle's own)."""
+    if stream is None:
+        return None
+    if isinstance(stream, int):
+        return C.c_void_p(stream)
+    return C.c_void_p(stream.cuda_stream)
+
+
+class AuvSim:
+    def __init__(self, cfg: dict, device: int = 0, ray_dirs=None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.cfg = dict(cfg)
+        self.device = int(device)
+        c = _lib.AuvConfig()
+        c.abi_version = _lib.ABI_VERSION
+        for k in ("n_envs", "n_rays", "n_circles", "n_polys", "n_verts", "max_steps"):
+            setattr(c, k, int(cfg[k]))
+        for k in ("dt", "sensor_range", "vessel_radius", "thrust_max", "moment_max",
+                  "look_ahead", "goal_radius"):
+            setattr(c, k, float(cfg[k]))
+        c.risk[:] = [float(x) for x in cfg["risk"]]
+        c.reward[:] = [float(x) for x in cfg["reward"]]
+        model = np.asarray(cfg["model"], dtype=np.float64)
+        if model.shape != (_lib.N_MODEL,):
+            raise ValueError(f"cfg['model'] must hold {_lib.N_MODEL} numbers")
+        c.model[:] = model.tolist()
+        rc = self._lib.auv_create(C.byref(c), self.device, C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise _lib.AuvError(rc, self._lib.auv_last_error(None).decode())
+        self.V, self.R = int(cfg["n_envs"]), int(cfg["n_rays"])
+        self.C, self.P, self.NV = int(cfg["n_circles"]), int(cfg["n_polys"]), int(cfg["n_verts"])
+        self.O = self.C + self.P
+        self.set_rays(ray_table(self.R) if ray_dirs is None else ray_dirs)
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.auv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _lib.AuvError(rc, self._lib.auv_last_error(self._h).decode())
+
+    # -- inputs -----------------------------------------------------------
+    def set_rays(self, ray_dirs):
+        self.ray_dirs = _f64(ray_dirs, (self.R, 2))
+        self._check(self._lib.auv_set_rays(self._h, _ptr(self.ray_dirs)))
+
+    def set_scene(self, scene: dict, env_begin: int = 0):
+        n = int(np.asarray(scene["circles"]).shape[0]) if self.C else int(np.asarray(scene["poly_pose"]).shape[0])
+        circles = _f64(scene["circles"], (n, self.C, 5)) if self.C else None
+        if self.P:
+            pose = _f64(scene["poly_pose"], (n, self.P, 6))
+            verts = _f64(scene["poly_verts"], (n, self.P, self.NV, 2))
+            nv = np.ascontiguousarray(scene["poly_nv"], dtype=np.int32)
+            if nv.shape != (n, self.P):
+                raise ValueError("poly_nv shape")
+            head = _f64(scene.get("poly_heading", np.zeros((n, self.P))), (n, self.P))
+        else:
+            pose = verts = nv = head = None
+        path = _f64(scene["path"], (n, 6)) if scene.get("path") is not None else None
+        self._check(self._lib.auv_set_scene(self._h, int(env_begin), n, _ptr(circles), _ptr(pose),
+                                            _ptr(verts), _ptr(nv), _ptr(head), _ptr(path)))
+
+    def reset(self, init_state, mask=None, stream=None):
+        init = _f64(init_state, (6, self.V))
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(np.asarray(mask).astype(bool), dtype=np.uint8)
+            if m.shape != (self.V,):
+                raise ValueError("mask shape")
+        self._check(self._lib.auv_reset(self._h, _ptr(m), _ptr(init), _stream_handle(stream)))
+
+    # -- stepping ---------------------------------------------------------
+    def step_host(self, action, stream=None):
+        a = _f64(action, (2, self.V))
+        self._check(self._lib.auv_step_host(self._h, _ptr(a), _stream_handle(stream)))
+
+    def step_device(self, action_ptr, stream=None):
+        """`action_ptr`: device address of f64 [2,V] (int), or None to reuse
+        the library's action buffer."""
+        p = None if action_ptr is None else C.c_void_p(int(action_ptr))
+        self._check(self._lib.auv_step(self._h, p, _stream_handle(stream)))
+
+    def sense(self, stream=None):
+        self._check(self._lib.auv_sense(self._h, _stream_handle(stream)))
+
+    def sync(self, stream=None):
+        self._check(self._lib.auv_sync(self._h, _stream_handle(stream)))
+
+    # -- outputs ----------------------------------------------------------
+    def buffer(self, name):
+        """(device pointer, shape tuple, auv_dtype) of a lent buffer."""
+        which = _lib.BUFFER_NAMES[name] if isinstance(name, str) else int(name)
+        p = C.c_void_p()
+        shape = (C.c_int64 * 4)()
+        nd = C.c_int32()
+        dt = C.c_int32()
+        self._check(self._lib.auv_get_buffer(self._h, which, C.byref(p), shape, C.byref(nd), C.byref(dt)))
+        return p.value, tuple(shape[i] for i in range(nd.value)), dt.value
+
+    def read(self, name, stream=None):
+        """Host copy of a buffer as a numpy array (synchronises)."""
+        which = _lib.BUFFER_NAMES[name] if isinstance(name, str) else int(name)
+        _, shape, dt = self.buffer(which)
+        out = np.empty(shape, dtype=_NP_DTYPE[dt])
+        self._check(self._lib.auv_read_buffer(self._h, which, _ptr(out), out.nbytes, _stream_handle(stream)))
+        return out
+
+    def tensor(self, name):
+        """torch tensor aliasing a device buffer through DLPack (zero-copy)."""
+        ptr, shape, dt = self.buffer(name)
+        return dlpack.to_torch(ptr, shape, dt, self.device, owner=self)
+
+    # -- profiling ----------------------------------------------------------
+    def profile(self, on: bool):
+        self._check(self._lib.auv_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        """({'dynamics','encounter','lidar'} -> total ms, steps) since the last read."""
+        ms = (C.c_double * 3)()
+        n = C.c_int64()
+        self._check(self._lib.auv_profile_read(self._h, ms, C.byref(n)))
+        return {"dynamics": ms[0], "encounter": ms[1], "lidar": ms[2]}, int(n.value)

@@ -1,0 +1,163 @@
+/*
+ * auvsim.h -- C ABI of libauvsim.so, the MI355X (gfx950) implementation of the
+ * gym-auv per-step simulation hot path: fp64 3-DOF vessel dynamics, moving
+ * obstacle advance, LiDAR ray-cast, signed obstacle distance / collision,
+ * per-obstacle encounter metadata + risk, and observation assembly, vectorised
+ * over V independent vessels (envs).
+ *
+ * The reference checkout (hebe2602/gym-auv @ v1) has no FFI or plugin layer
+ * and does not contain the simulator itself; the interfaces below replace the
+ * gym env contract as the mounted consumers see it:
+ *   - observation dict {"perception": (B,1,180) closeness, "navigation":
+ *     (B,1,6)}                                  radarCNN.py:165-175,184-193,215-262
+ *   - closeness = 1 - range/150, 180 rays       utils/dataloader.py:13,56
+ *   - metadata / risk dataset rows              utils/explore_dataset.py:40-53,
+ *                                               utils/dataloader.py:104-120
+ * Each entry point names the consumer-side line it serves.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success or a negative auv_status; no exception crosses the boundary.  One
+ * handle per GPU per process; calls on one handle must be serialised by the
+ * caller.  Device buffers are owned by the library and lent out by
+ * auv_get_buffer() for the life of the handle.  Kernels are enqueued on the
+ * stream given to the call (NULL = the handle's own stream), so a PyTorch
+ * caller orders against them by passing its current stream.
+ */
+#ifndef AUVSIM_H
+#define AUVSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AUVSIM_ABI_VERSION 1
+#define AUV_N_MODEL 16
+#define AUV_NAV_FEATURES 6   /* radarCNN.py:185 */
+#define AUV_META_FIELDS 5    /* utils/explore_dataset.py:45 */
+
+typedef struct auv_sim* auv_handle;
+
+typedef enum auv_status {
+    AUV_OK = 0,
+    AUV_ERR_ARG = -1,      /* bad argument / shape */
+    AUV_ERR_DEVICE = -2,   /* no usable GPU, or a HIP call failed */
+    AUV_ERR_MEMORY = -3,   /* device allocation failed */
+    AUV_ERR_STATE = -4     /* call order (e.g. step before set_scene/reset) */
+} auv_status;
+
+/* Static description of one simulation batch.  Obstacle ids within an env:
+ * circles 0..n_circles-1, then polygons n_circles..n_circles+n_polys-1. */
+typedef struct auv_config {
+    int32_t abi_version;    /* AUVSIM_ABI_VERSION */
+    int32_t n_envs;         /* V  vessels, one per env */
+    int32_t n_rays;         /* R  (180: utils/dataloader.py:13) */
+    int32_t n_circles;      /* C  circle slots per env */
+    int32_t n_polys;        /* P  polygon slots per env */
+    int32_t n_verts;        /* NV vertex slots per polygon (3..16) */
+    int32_t max_steps;      /* truncation horizon */
+    int32_t reserved;
+    double dt;              /* integrator step, s */
+    double sensor_range;    /* 150 m: utils/dataloader.py:56 */
+    double vessel_radius;
+    double thrust_max;
+    double moment_max;
+    double look_ahead;
+    double goal_radius;
+    double risk[3];         /* w_d, w_c, T_c of the default risk index */
+    double reward[4];       /* w_progress, w_collision, w_goal, w_cross_track */
+    double model[AUV_N_MODEL];
+} auv_config;
+
+typedef enum auv_dtype { AUV_F64 = 0, AUV_F32 = 1, AUV_I32 = 2, AUV_U8 = 3, AUV_I64 = 4 } auv_dtype;
+
+/* Device buffers a caller may borrow (shape in elements). */
+typedef enum auv_buffer {
+    AUV_BUF_STATE = 0,       /* f64 [6,V]   x,y,psi,u,v,r (SoA) */
+    AUV_BUF_ACTION = 1,      /* f64 [2,V]   staging for auv_step_host / action == NULL */
+    AUV_BUF_RANGES = 2,      /* f64 [V,R]   metres, sensor_range when nothing hit */
+    AUV_BUF_HIT = 3,         /* i32 [V,R]   obstacle id, -1 when nothing hit */
+    AUV_BUF_PERCEPTION = 4,  /* f32 [V,1,R] obs["perception"], radarCNN.py:275 */
+    AUV_BUF_NAVIGATION = 5,  /* f32 [V,1,6] obs["navigation"], radarCNN.py:190-193 */
+    AUV_BUF_OBST_DIST = 6,   /* f64 [V,O]   signed hull distance, +inf if absent */
+    AUV_BUF_RISK = 7,        /* f64 [V,O]   risk_*.csv values, utils/dataloader.py:108 */
+    AUV_BUF_META = 8,        /* f64 [V,O,5] utils/explore_dataset.py:45 */
+    AUV_BUF_OWN = 9,         /* f64 [V,2]   speed_OS, heading_OS, utils/explore_dataset.py:8 */
+    AUV_BUF_COLLISION = 10,  /* u8  [V] */
+    AUV_BUF_REACHED_GOAL = 11, /* u8 [V] */
+    AUV_BUF_TRUNCATED = 12,  /* u8  [V] */
+    AUV_BUF_DONE = 13,       /* u8  [V] */
+    AUV_BUF_MIN_DIST = 14,   /* f64 [V] */
+    AUV_BUF_MIN_IDX = 15,    /* i32 [V] */
+    AUV_BUF_ALONG = 16,      /* f64 [V]   along-track position on the path */
+    AUV_BUF_T_STEP = 17,     /* i32 [V] */
+    AUV_BUF_CIRCLES = 18,    /* f64 [V,C,5] cx,cy,rad,vx,vy */
+    AUV_BUF_POLY_POSE = 19,  /* f64 [V,P,6] X,Y,cos h,sin h,vx,vy */
+    AUV_BUF_REWARD = 20,     /* f64 [V]   reward of the last step (0 after reset) */
+    AUV_BUF_COUNT = 21
+} auv_buffer;
+
+/* Library build information: "libauvsim <abi> gfx950 ...". */
+const char* auv_version(void);
+
+/* Last error text of a handle, or (h == NULL) of the calling thread's last
+ * failed auv_create. */
+const char* auv_last_error(auv_handle h);
+
+/* Create a batch on HIP device `device`.  Replaces constructing the env
+ * (consumer: PerceptionNavigationExtractor.__init__, radarCNN.py:202-267,
+ * which reads the observation space this config implies). */
+int auv_create(const auv_config* cfg, int device, auv_handle* out);
+void auv_destroy(auv_handle h);
+
+/* Body-frame ray directions, host f64 [R,2] = (cos, sin) per ray. */
+int auv_set_rays(auv_handle h, const double* ray_dirs);
+
+/* Upload scene data for envs [env_begin, env_begin+env_count); all host
+ * pointers: circles f64 [n,C,5], poly_pose f64 [n,P,6], poly_verts f64
+ * [n,P,NV,2], poly_nv i32 [n,P], poly_heading f64 [n,P], path f64 [n,6].
+ * A pointer may be NULL when its slot count is 0 (path NULL keeps paths). */
+int auv_set_scene(auv_handle h, int32_t env_begin, int32_t env_count,
+                  const double* circles, const double* poly_pose,
+                  const double* poly_verts, const int32_t* poly_nv,
+                  const double* poly_heading, const double* path);
+
+/* gym reset(): host init_state f64 [6,V]; mask u8 [V] or NULL (= all envs).
+ * Resets the selected envs (vessel state, step counter, obstacles back to
+ * their uploaded poses), then senses.
+ * Observation consumer: radarCNN.py:270-280. */
+int auv_reset(auv_handle h, const uint8_t* mask, const double* init_state, void* stream);
+
+/* gym step(): action is a DEVICE pointer f64 [2,V] (surge in [0,1], steer in
+ * [-1,1]) or NULL to use AUV_BUF_ACTION.  Advances obstacles, integrates the
+ * vessels, then senses.  Asynchronous on `stream`. */
+int auv_step(auv_handle h, const double* action, void* stream);
+
+/* Same with a HOST action pointer (copied to AUV_BUF_ACTION first). */
+int auv_step_host(auv_handle h, const double* action, void* stream);
+
+/* Recompute every output from the current state without advancing time. */
+int auv_sense(auv_handle h, void* stream);
+
+/* Borrow a device buffer: pointer, shape (up to 4 dims), ndim, auv_dtype. */
+int auv_get_buffer(auv_handle h, int which, void** dev_ptr, int64_t* shape,
+                   int32_t* ndim, int32_t* dtype);
+
+/* Copy a buffer to host memory (synchronises `stream`). */
+int auv_read_buffer(auv_handle h, int which, void* host_dst, int64_t nbytes, void* stream);
+
+/* Block until all work enqueued on `stream` (NULL = the handle's) is done. */
+int auv_sync(auv_handle h, void* stream);
+
+/* Per-kernel device timing.  While enabled, auv_step brackets each kernel
+ * with HIP events on the launch stream.  auv_profile_read synchronises and
+ * returns the accumulated milliseconds per kernel {dynamics, encounter,
+ * lidar} and the number of steps they cover, then clears the accumulators. */
+int auv_profile_enable(auv_handle h, int32_t on);
+int auv_profile_read(auv_handle h, double ms[3], int64_t* n_steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUVSIM_H */

@@ -1,0 +1,631 @@
+"""CPU oracle for the AUV simulation hot path (TEST INFRASTRUCTURE ONLY).
+
+This module is the normative fp64 numpy restatement of the per-step path:
+3-DOF vessel dynamics, moving-obstacle advance, LiDAR ray-cast, signed
+obstacle distances / collision flag, per-obstacle encounter metadata and risk,
+and observation assembly.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it; the product path never
+does.
+
+PARITY UNPINNED for dynamics, obstacle advance, LiDAR, collision and risk:
+the reference checkout (hebe2602/gym-auv @ v1) does not contain the simulator
+(`radarCNN.py:232` only names the absent ``gym_auv/`` package), so there is no
+reference function, golden vector or fixture to pin these against.  What the
+mounted files do constrain is restated here with citations:
+
+* scan width 180 and maximum range 150 m          -> utils/dataloader.py:13,56,127
+* closeness observation ``1 - range/150``          -> utils/dataloader.py:56
+* scan wraps over the full circle (circular pad)   -> models/lidar_cnn_shallow.py:30
+* observation dict {"perception": (B,1,180), "navigation": (B,1,6)}
+                                                   -> radarCNN.py:165-175,184-193,215-262
+* metadata row [speed_OS, heading_OS, (heading_ts, dist, speed, bearing,
+  course) x n]; static obstacle <=> heading_ts == 0 and speed == speed_OS
+                                                   -> utils/explore_dataset.py:8,40-53
+* risk label reduction max / sum / mean over <= 8 per-obstacle risks
+                                                   -> utils/dataloader.py:104-120
+
+Arithmetic contract (this is what makes GPU-vs-oracle comparisons bit-exact
+instead of tolerance-based): every quantity is IEEE-754 binary64, computed
+with *unfused* +, -, *, /, sqrt, floor, rint in exactly the operation order
+written below.  sin/cos/atan2 are not taken from libm: they are the fixed
+polynomial sequences `sincos` / `atan2` in this file, so that every
+implementation of the contract produces identical bits.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# ----------------------------------------------------------------------------
+# constants of the arithmetic contract
+# ----------------------------------------------------------------------------
+PI = float.fromhex("0x1.921fb54442d18p+1")
+TWO_PI = float.fromhex("0x1.921fb54442d18p+2")
+INV_TWO_PI = float.fromhex("0x1.45f306dc9c883p-3")
+PIO2 = float.fromhex("0x1.921fb54442d18p+0")
+PIO4 = float.fromhex("0x1.921fb54442d18p-1")
+PIO8 = float.fromhex("0x1.921fb54442d18p-2")
+TWO_OVER_PI = float.fromhex("0x1.45f306dc9c883p-1")
+# pi/2 split: HI holds the leading 26 mantissa bits, so k*HI is exact for |k| < 2**27.
+PIO2_HI = float.fromhex("0x1.921fb50000000p+0")
+PIO2_LO = float.fromhex("0x1.110b4611a6263p-26")
+
+# Taylor coefficients (-1)^j/(2j+1)!, j = 1..8 and (-1)^j/(2j)!, j = 1..9;
+# truncation error on |r| <= pi/4 is below 1e-19.
+SIN_C = (-0.16666666666666666, 0.008333333333333333, -0.0001984126984126984,
+         2.7557319223985893e-06, -2.505210838544172e-08, 1.6059043836821613e-10,
+         -7.647163731819816e-13, 2.8114572543455206e-15)
+COS_C = (-0.5, 0.041666666666666664, -0.001388888888888889, 2.48015873015873e-05,
+         -2.755731922398589e-07, 2.08767569878681e-09, -1.1470745597729725e-11,
+         4.779477332387385e-14, -1.5619206968586225e-16)
+
+# atan argument reduction: z in [0,1] is moved to |w| <= tan(pi/16) around
+# one of atan^-1{0, pi/8, pi/4}; series (-1)^k/(2k+1), k = 1..11.
+ATAN_T1 = 0.198912367379658      # tan(pi/16)
+ATAN_T3 = 0.6681786379192989     # tan(3pi/16)
+TAN_PIO8 = float.fromhex("0x1.a827999fcef32p-2")
+ATAN_C = tuple(((-1.0) ** k) / (2 * k + 1) for k in range(1, 12))
+
+# RKF45 (Fehlberg) tableau, 5th-order solution propagated.
+RK_A = (
+    (),
+    (1.0 / 4.0,),
+    (3.0 / 32.0, 9.0 / 32.0),
+    (1932.0 / 2197.0, -7200.0 / 2197.0, 7296.0 / 2197.0),
+    (439.0 / 216.0, -8.0, 3680.0 / 513.0, -845.0 / 4104.0),
+    (-8.0 / 27.0, 2.0, -3544.0 / 2565.0, 1859.0 / 4104.0, -11.0 / 40.0),
+)
+RK_B5 = (16.0 / 135.0, 0.0, 6656.0 / 12825.0, 28561.0 / 56430.0, -9.0 / 50.0, 2.0 / 55.0)
+
+# indices into the model-constant vector `mp` (length 16); values are supplied
+# by the caller so that oracle and device use identical numbers.
+(MP_MINV11, MP_MINV22, MP_MINV23, MP_MINV32, MP_MINV33,
+ MP_M11, MP_M22, MP_M23,
+ MP_XU, MP_XUU, MP_YV, MP_YVV, MP_YR, MP_NV, MP_NR, MP_NRR) = range(16)
+
+NAV_FEATURES = 6
+META_FIELDS = 5   # heading_ts, dist, speed, bearing, course
+
+
+# ----------------------------------------------------------------------------
+# elementary functions of the contract
+# ----------------------------------------------------------------------------
+def sincos(x):
+    """(sin x, cos x) by two-term Cody-Waite reduction and Taylor-Horner."""
+    x = np.asarray(x, dtype=np.float64)
+    k = np.rint(x * TWO_OVER_PI)
+    r = (x - k * PIO2_HI) - k * PIO2_LO
+    r2 = r * r
+    ps = np.full_like(r, SIN_C[-1])
+    for c in SIN_C[-2::-1]:
+        ps = c + r2 * ps
+    sr = r + (r * r2) * ps
+    pc = np.full_like(r, COS_C[-1])
+    for c in COS_C[-2::-1]:
+        pc = c + r2 * pc
+    cr = 1.0 + r2 * pc
+    q = k.astype(np.int64) & 3
+    s = np.where(q == 0, sr, np.where(q == 1, cr, np.where(q == 2, -sr, -cr)))
+    c = np.where(q == 0, cr, np.where(q == 1, -sr, np.where(q == 2, -cr, sr)))
+    return s, c
+
+
+def atan2(y, x):
+    """Four-quadrant arctangent of the contract; atan2(0, 0) = 0."""
+    y = np.asarray(y, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    y, x = np.broadcast_arrays(y, x)
+    ax = np.abs(x)
+    ay = np.abs(y)
+    zero = (ax == 0.0) & (ay == 0.0)
+    swap = ay > ax
+    num = np.where(swap, ax, ay)
+    den = np.where(swap, ay, ax)
+    den = np.where(zero, 1.0, den)
+    z = num / den
+    c = np.where(z > ATAN_T3, 1.0, np.where(z > ATAN_T1, TAN_PIO8, 0.0))
+    base = np.where(z > ATAN_T3, PIO4, np.where(z > ATAN_T1, PIO8, 0.0))
+    w = (z - c) / (1.0 + z * c)
+    w2 = w * w
+    p = np.full_like(w, ATAN_C[-1])
+    for a in ATAN_C[-2::-1]:
+        p = a + w2 * p
+    a = base + (w + (w * w2) * p)
+    a = np.where(swap, PIO2 - a, a)
+    a = np.where(x < 0.0, PI - a, a)
+    a = np.where(y < 0.0, -a, a)
+    return np.where(zero, 0.0, a)
+
+
+def wrap_angle(a):
+    """Map an angle to [-pi, pi)."""
+    a = np.asarray(a, dtype=np.float64)
+    k = np.floor((a + PI) * INV_TWO_PI)
+    return a - k * TWO_PI
+
+
+# ----------------------------------------------------------------------------
+# a1: vessel dynamics
+# ----------------------------------------------------------------------------
+def vessel_rhs(y, fx, mz, mp):
+    """Time derivative of y = [x, y, psi, u, v, r] (arrays of shape [6, V])."""
+    psi, u, v, r = y[2], y[3], y[4], y[5]
+    s, c = sincos(psi)
+    xd = c * u - s * v
+    yd = s * u + c * v
+    c13 = -(mp[MP_M22] * v + mp[MP_M23] * r)
+    c23 = mp[MP_M11] * u
+    cor1 = c13 * r
+    cor2 = c23 * r
+    cor3 = -(c13 * u) - c23 * v
+    d1 = (mp[MP_XU] + mp[MP_XUU] * np.abs(u)) * u
+    d2 = (mp[MP_YV] + mp[MP_YVV] * np.abs(v)) * v + mp[MP_YR] * r
+    d3 = mp[MP_NV] * v + (mp[MP_NR] + mp[MP_NRR] * np.abs(r)) * r
+    r1 = (fx - cor1) - d1
+    r2 = (0.0 - cor2) - d2
+    r3 = (mz - cor3) - d3
+    ud = mp[MP_MINV11] * r1
+    vd = mp[MP_MINV22] * r2 + mp[MP_MINV23] * r3
+    rd = mp[MP_MINV32] * r2 + mp[MP_MINV33] * r3
+    return np.stack([xd, yd, r, ud, vd, rd])
+
+
+def step_dynamics(state, action, cfg):
+    """One RKF45 step of size cfg['dt'].  state [6,V], action [2,V] -> [6,V].
+
+    action[0] in [0,1] scales the surge force, action[1] in [-1,1] the yaw
+    moment; both are clipped first.
+    """
+    mp = cfg["model"]
+    h = cfg["dt"]
+    fx = np.minimum(np.maximum(action[0], 0.0), 1.0) * cfg["thrust_max"]
+    mz = np.minimum(np.maximum(action[1], -1.0), 1.0) * cfg["moment_max"]
+    k = []
+    for i in range(6):
+        if i == 0:
+            yi = state
+        else:
+            acc = RK_A[i][0] * k[0]
+            for j in range(1, i):
+                acc = acc + RK_A[i][j] * k[j]
+            yi = state + h * acc
+        k.append(vessel_rhs(yi, fx, mz, mp))
+    acc = RK_B5[0] * k[0]
+    for j in (2, 3, 4, 5):
+        acc = acc + RK_B5[j] * k[j]
+    out = state + h * acc
+    out[2] = wrap_angle(out[2])
+    return out
+
+
+# ----------------------------------------------------------------------------
+# a2: obstacle advance
+# ----------------------------------------------------------------------------
+def advance_obstacles(circles, poly_pose, dt):
+    """Constant-velocity advance, in place.  circles [V,C,5] = (cx,cy,rad,vx,vy);
+    poly_pose [V,P,6] = (X,Y,cos h,sin h,vx,vy)."""
+    circles[..., 0] = circles[..., 0] + circles[..., 3] * dt
+    circles[..., 1] = circles[..., 1] + circles[..., 4] * dt
+    poly_pose[..., 0] = poly_pose[..., 0] + poly_pose[..., 4] * dt
+    poly_pose[..., 1] = poly_pose[..., 1] + poly_pose[..., 5] * dt
+
+
+def polygon_world_vertices(poly_pose, poly_verts):
+    """Body-frame vertices [V,P,NV,2] -> world frame."""
+    X = poly_pose[..., 0][..., None]
+    Y = poly_pose[..., 1][..., None]
+    ch = poly_pose[..., 2][..., None]
+    sh = poly_pose[..., 3][..., None]
+    bx = poly_verts[..., 0]
+    by = poly_verts[..., 1]
+    wx = X + (ch * bx - sh * by)
+    wy = Y + (sh * bx + ch * by)
+    return wx, wy
+
+
+# ----------------------------------------------------------------------------
+# a3: LiDAR
+# ----------------------------------------------------------------------------
+def lidar(state, circles, poly_pose, poly_verts, poly_nv, ray_dirs, sensor_range):
+    """Nearest boundary hit per ray.
+
+    Returns (ranges [V,R] f64, hit [V,R] i32).  Obstacle ids: circles
+    0..C-1, polygons C..C+P-1; -1 and range = sensor_range when nothing is
+    hit.  The running best starts at sensor_range; primitives are visited in
+    id order (polygon edges in vertex order) and a hit at parameter t replaces
+    the best only when 0 <= t < best, so ties keep the lowest id and a hit at
+    exactly sensor_range does not count.
+    """
+    V = state.shape[1]
+    R = ray_dirs.shape[0]
+    C = circles.shape[1]
+    P = poly_pose.shape[1]
+    px = state[0][:, None]
+    py = state[1][:, None]
+    s, c = sincos(state[2])
+    cb = ray_dirs[:, 0][None, :]
+    sb = ray_dirs[:, 1][None, :]
+    dx = c[:, None] * cb - s[:, None] * sb
+    dy = s[:, None] * cb + c[:, None] * sb
+    best = np.full((V, R), sensor_range, dtype=np.float64)
+    hit = np.full((V, R), -1, dtype=np.int32)
+
+    def consider(t, valid, oid):
+        nonlocal best, hit
+        upd = valid & (t >= 0.0) & (t < best)
+        best = np.where(upd, t, best)
+        hit = np.where(upd, np.int32(oid), hit)
+
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for j in range(C):
+            rad = circles[:, j, 2][:, None]
+            mx = circles[:, j, 0][:, None] - px
+            my = circles[:, j, 1][:, None] - py
+            cc = (mx * mx + my * my) - rad * rad
+            b = mx * dx + my * dy
+            disc = b * b - cc
+            ok = (rad > 0.0) & (disc >= 0.0)
+            sq = np.sqrt(np.where(ok, disc, 0.0))
+            t = b - sq
+            t = np.where(t < 0.0, b + sq, t)
+            consider(t, ok, j)
+        if P:
+            wx, wy = polygon_world_vertices(poly_pose, poly_verts)
+            NV = poly_verts.shape[2]
+            for p in range(P):
+                nv = poly_nv[:, p]
+                for k in range(NV):
+                    k1 = np.where(k + 1 < nv, k + 1, 0)
+                    Ax = wx[:, p, k]
+                    Ay = wy[:, p, k]
+                    Bx = np.take_along_axis(wx[:, p, :], k1[:, None], axis=1)[:, 0]
+                    By = np.take_along_axis(wy[:, p, :], k1[:, None], axis=1)[:, 0]
+                    ax = (Ax - state[0])[:, None]
+                    ay = (Ay - state[1])[:, None]
+                    ex = (Bx - Ax)[:, None]
+                    ey = (By - Ay)[:, None]
+                    nt = ax * ey - ay * ex
+                    den = dx * ey - dy * ex
+                    ns = ax * dy - ay * dx
+                    inseg = np.where(den > 0.0, (ns >= 0.0) & (ns <= den),
+                                     (ns <= 0.0) & (ns >= den))
+                    ok = (k < nv)[:, None] & (den != 0.0) & inseg
+                    t = nt / np.where(ok, den, 1.0)
+                    consider(t, ok, C + p)
+    return best, hit
+
+
+# ----------------------------------------------------------------------------
+# a4: signed obstacle distances and the collision predicate
+# ----------------------------------------------------------------------------
+def obstacle_distances(state, circles, poly_pose, poly_verts, poly_nv, vessel_radius):
+    """Signed hull distance per obstacle: (centre-to-surface distance, negative
+    inside the obstacle) minus vessel_radius.  Absent obstacles give +inf.
+    Returns (dist [V,C+P], collision u8 [V], min_dist [V], min_idx i32 [V]);
+    collision <=> some dist < 0; min_idx = lowest id attaining the minimum
+    (-1 when the env has no obstacle)."""
+    V = state.shape[1]
+    C = circles.shape[1]
+    P = poly_pose.shape[1]
+    dist = np.full((V, C + P), np.inf, dtype=np.float64)
+    px, py = state[0], state[1]
+    for j in range(C):
+        rad = circles[:, j, 2]
+        mx = circles[:, j, 0] - px
+        my = circles[:, j, 1] - py
+        d = (np.sqrt(mx * mx + my * my) - rad) - vessel_radius
+        dist[:, j] = np.where(rad > 0.0, d, np.inf)
+    if P:
+        wx, wy = polygon_world_vertices(poly_pose, poly_verts)
+        NV = poly_verts.shape[2]
+        for p in range(P):
+            nv = poly_nv[:, p]
+            dmin = np.full(V, np.inf)
+            inside = np.zeros(V, dtype=bool)
+            for k in range(NV):
+                k1 = np.where(k + 1 < nv, k + 1, 0)
+                Ax = wx[:, p, k]
+                Ay = wy[:, p, k]
+                Bx = np.take_along_axis(wx[:, p, :], k1[:, None], axis=1)[:, 0]
+                By = np.take_along_axis(wy[:, p, :], k1[:, None], axis=1)[:, 0]
+                ax = Ax - px
+                ay = Ay - py
+                by = By - py
+                ex = Bx - Ax
+                ey = By - Ay
+                ee = ex * ex + ey * ey
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    tp = (0.0 - (ax * ex + ay * ey)) / np.where(ee > 0.0, ee, 1.0)
+                tp = np.where(ee > 0.0, np.minimum(np.maximum(tp, 0.0), 1.0), 0.0)
+                qx = ax + tp * ex
+                qy = ay + tp * ey
+                d = np.sqrt(qx * qx + qy * qy)
+                act = k < nv
+                dmin = np.where(act & (d < dmin), d, dmin)
+                nt = ax * ey - ay * ex
+                up = (ay <= 0.0) & (by > 0.0) & (nt > 0.0)
+                dn = (by <= 0.0) & (ay > 0.0) & (nt < 0.0)
+                inside = inside ^ (act & (up | dn))
+            d = np.where(inside, -dmin, dmin) - vessel_radius
+            dist[:, C + p] = np.where(nv > 0, d, np.inf)
+    if C + P:
+        min_idx = np.argmin(dist, axis=1).astype(np.int32)
+        min_dist = dist[np.arange(V), min_idx]
+        min_idx = np.where(np.isinf(min_dist), np.int32(-1), min_idx)
+    else:
+        min_idx = np.full(V, -1, dtype=np.int32)
+        min_dist = np.full(V, np.inf)
+    collision = (min_dist < 0.0).astype(np.uint8)
+    return dist, collision, min_dist, min_idx
+
+
+# ----------------------------------------------------------------------------
+# a5: per-obstacle encounter metadata and risk
+# ----------------------------------------------------------------------------
+def encounter_metadata(state, circles, poly_pose, poly_heading, dist):
+    """Per obstacle [heading_ts, dist, speed, bearing, course] (layout of
+    utils/explore_dataset.py:45) plus own [speed, heading].
+
+    heading_ts: obstacle heading (0 for circles); dist: signed hull distance;
+    speed: |v_obstacle - v_own|; bearing: direction to the obstacle centre
+    relative to own heading; course: direction of the relative velocity
+    relative to own heading (0 when the relative velocity is zero).
+    Returns (own [V,2], meta [V,C+P,5])."""
+    V = state.shape[1]
+    C = circles.shape[1]
+    P = poly_pose.shape[1]
+    px, py, psi, u, v = state[0], state[1], state[2], state[3], state[4]
+    s, c = sincos(psi)
+    vox = c * u - s * v
+    voy = s * u + c * v
+    own = np.stack([np.sqrt(vox * vox + voy * voy), psi], axis=1)
+    meta = np.zeros((V, C + P, META_FIELDS), dtype=np.float64)
+    for o in range(C + P):
+        if o < C:
+            cx, cy = circles[:, o, 0], circles[:, o, 1]
+            vx, vy = circles[:, o, 3], circles[:, o, 4]
+            hd = np.zeros(V)
+        else:
+            q = o - C
+            cx, cy = poly_pose[:, q, 0], poly_pose[:, q, 1]
+            vx, vy = poly_pose[:, q, 4], poly_pose[:, q, 5]
+            hd = poly_heading[:, q]
+        mx = cx - px
+        my = cy - py
+        rvx = vx - vox
+        rvy = vy - voy
+        meta[:, o, 0] = hd
+        meta[:, o, 1] = dist[:, o]
+        meta[:, o, 2] = np.sqrt(rvx * rvx + rvy * rvy)
+        meta[:, o, 3] = wrap_angle(atan2(my, mx) - psi)
+        meta[:, o, 4] = wrap_angle(atan2(rvy, rvx) - psi)
+    return own, meta
+
+
+def risk_default(state, circles, poly_pose, dist, sensor_range, rp):
+    """SELF-DEFINED default collision-risk index in [0,1) per obstacle.
+
+    The reference's CRI formula is not in the checkout (only its outputs,
+    data/risk_*.csv); this default is a closest-point-of-approach index:
+
+        risk = w_d * (1 - d/R)^2 + w_c * (1 - dcpa/R)^2 * Tc/(Tc + tcpa)
+
+    for obstacles with hull distance d in [0, R) (d clipped at 0), 0 outside
+    sensor range; the second term only when the obstacle is closing
+    (tcpa > 0).  rp = (w_d, w_c, Tc).  dcpa / tcpa use obstacle centres and
+    the relative velocity."""
+    V = state.shape[1]
+    C = circles.shape[1]
+    P = poly_pose.shape[1]
+    px, py, psi, u, v = state[0], state[1], state[2], state[3], state[4]
+    s, c = sincos(psi)
+    vox = c * u - s * v
+    voy = s * u + c * v
+    w_d, w_c, t_c = rp
+    risk = np.zeros((V, C + P), dtype=np.float64)
+    for o in range(C + P):
+        if o < C:
+            cx, cy = circles[:, o, 0], circles[:, o, 1]
+            vx, vy = circles[:, o, 3], circles[:, o, 4]
+        else:
+            q = o - C
+            cx, cy = poly_pose[:, q, 0], poly_pose[:, q, 1]
+            vx, vy = poly_pose[:, q, 4], poly_pose[:, q, 5]
+        mx = cx - px
+        my = cy - py
+        rvx = vx - vox
+        rvy = vy - voy
+        d = np.maximum(dist[:, o], 0.0)
+        inrange = d < sensor_range
+        fd = 1.0 - np.where(inrange, d, 0.0) / sensor_range
+        term_d = w_d * (fd * fd)
+        vv = rvx * rvx + rvy * rvy
+        closing = 0.0 - (mx * rvx + my * rvy)
+        has_c = (vv > 0.0) & (closing > 0.0)
+        tcpa = np.where(has_c, closing, 0.0) / np.where(has_c, vv, 1.0)
+        qx = mx + rvx * tcpa
+        qy = my + rvy * tcpa
+        dcpa = np.sqrt(qx * qx + qy * qy)
+        fc = 1.0 - np.minimum(dcpa, sensor_range) / sensor_range
+        term_c = (w_c * (fc * fc)) * (t_c / (t_c + tcpa))
+        r = term_d + np.where(has_c, term_c, 0.0)
+        risk[:, o] = np.where(inrange, r, 0.0)
+    return risk
+
+
+# ----------------------------------------------------------------------------
+# a7: observation assembly
+# ----------------------------------------------------------------------------
+def navigation_features(state, path, look_ahead):
+    """[u, v, r, look-ahead heading error, heading error, cross-track error]
+    with respect to a straight path per env; path [V,6] =
+    (x0, y0, angle, cos angle, sin angle, length).  Also returns along-track
+    position s [V]."""
+    px, py, psi = state[0], state[1], state[2]
+    x0, y0, ang, ca, sa = path[:, 0], path[:, 1], path[:, 2], path[:, 3], path[:, 4]
+    rx = px - x0
+    ry = py - y0
+    along = rx * ca + ry * sa
+    cte = ry * ca - rx * sa
+    tx = x0 + (along + look_ahead) * ca
+    ty = y0 + (along + look_ahead) * sa
+    la = wrap_angle(atan2(ty - py, tx - px) - psi)
+    he = wrap_angle(ang - psi)
+    nav = np.stack([state[3], state[4], state[5], la, he, cte], axis=1)
+    return nav, along
+
+
+def closeness(ranges, sensor_range):
+    """Perception observation 1 - range/sensor_range (utils/dataloader.py:56),
+    rounded once to fp32, shape [V,1,R]."""
+    return (1.0 - ranges / sensor_range).astype(np.float32)[:, None, :]
+
+
+# ----------------------------------------------------------------------------
+# the whole step, in the order the device path runs it
+# ----------------------------------------------------------------------------
+class OracleEnv:
+    """Vectorised CPU env with the same buffers as the device library."""
+
+    def __init__(self, cfg, ray_dirs):
+        self.cfg = cfg
+        self.ray_dirs = np.ascontiguousarray(ray_dirs, dtype=np.float64)
+        V = cfg["n_envs"]
+        self.state = np.zeros((6, V))
+        self.t_step = np.zeros(V, dtype=np.int32)
+        self.path = np.zeros((V, 6))
+        self.path[:, 3] = 1.0
+
+    def set_scene(self, circles, poly_pose, poly_verts, poly_nv, poly_heading=None):
+        self.circles = np.array(circles, dtype=np.float64, copy=True)
+        self.poly_pose = np.array(poly_pose, dtype=np.float64, copy=True)
+        self.poly_verts = np.array(poly_verts, dtype=np.float64, copy=True)
+        self.poly_nv = np.array(poly_nv, dtype=np.int32, copy=True)
+        if poly_heading is None:
+            poly_heading = np.zeros(self.poly_pose.shape[:2])
+        self.poly_heading = np.array(poly_heading, dtype=np.float64, copy=True)
+        self.circles0 = self.circles.copy()
+        self.poly_pose0 = self.poly_pose.copy()
+
+    def set_path(self, path):
+        self.path = np.array(path, dtype=np.float64, copy=True)
+
+    def reset(self, init_state, mask=None):
+        init_state = np.asarray(init_state, dtype=np.float64)
+        # a reset also puts the env's obstacles back where they were uploaded
+        if mask is None:
+            self.state = init_state.copy()
+            self.t_step[:] = 0
+            self.circles = self.circles0.copy()
+            self.poly_pose = self.poly_pose0.copy()
+        else:
+            m = np.asarray(mask).astype(bool)
+            self.state[:, m] = init_state[:, m]
+            self.t_step[m] = 0
+            self.circles[m] = self.circles0[m]
+            self.poly_pose[m] = self.poly_pose0[m]
+        self.sense()
+
+    def sense(self, is_step=False):
+        cfg = self.cfg
+        R = cfg["sensor_range"]
+        self.ranges, self.hit = lidar(self.state, self.circles, self.poly_pose,
+                                      self.poly_verts, self.poly_nv, self.ray_dirs, R)
+        (self.obst_dist, self.collision, self.min_dist,
+         self.min_idx) = obstacle_distances(self.state, self.circles, self.poly_pose,
+                                            self.poly_verts, self.poly_nv,
+                                            cfg["vessel_radius"])
+        self.own, self.meta = encounter_metadata(self.state, self.circles, self.poly_pose,
+                                                 self.poly_heading, self.obst_dist)
+        self.risk = risk_default(self.state, self.circles, self.poly_pose, self.obst_dist,
+                                 R, cfg["risk"])
+        self.perception = closeness(self.ranges, R)
+        prev_along = getattr(self, "along", None)
+        nav, self.along = navigation_features(self.state, self.path, cfg["look_ahead"])
+        self.navigation = nav.astype(np.float32)[:, None, :]
+        self.reached_goal = ((self.path[:, 5] - self.along) <= cfg["goal_radius"]).astype(np.uint8)
+        self.truncated = (self.t_step >= cfg["max_steps"]).astype(np.uint8)
+        self.done = (self.collision | self.reached_goal | self.truncated).astype(np.uint8)
+        if is_step:
+            w_p, w_col, w_g, w_cte = cfg["reward"]
+            rew = w_p * (self.along - prev_along)
+            rew = rew - w_cte * np.abs(nav[:, 5])
+            rew = rew - np.where(self.collision != 0, w_col, 0.0)
+            rew = rew + np.where(self.reached_goal != 0, w_g, 0.0)
+            self.reward = rew
+        else:
+            self.reward = np.zeros(self.state.shape[1])
+
+    def step(self, action):
+        cfg = self.cfg
+        action = np.asarray(action, dtype=np.float64)
+        advance_obstacles(self.circles, self.poly_pose, cfg["dt"])
+        self.state = step_dynamics(self.state, action, cfg)
+        self.t_step = self.t_step + 1
+        self.sense(is_step=True)
+
+
+# ----------------------------------------------------------------------------
+# scalar (one vessel, pure Python float) forms used to cross-check the
+# vectorised code on small cases
+# ----------------------------------------------------------------------------
+def lidar_scalar(p, psi, circles, polys_world, ray_dirs, sensor_range):
+    """p = (x, y); circles = [(cx, cy, rad)]; polys_world = list of vertex
+    lists [(x, y), ...] (empty list = absent).  Python-float restatement of
+    `lidar` for one vessel."""
+    import math
+    s, c = sincos(np.float64(psi))
+    s = float(s)
+    c = float(c)
+    out_r = []
+    out_i = []
+    for i in range(len(ray_dirs)):
+        cb = float(ray_dirs[i][0])
+        sb = float(ray_dirs[i][1])
+        dx = c * cb - s * sb
+        dy = s * cb + c * sb
+        best = sensor_range
+        hit = -1
+        for j, (cx, cy, rad) in enumerate(circles):
+            if not rad > 0.0:
+                continue
+            mx = cx - p[0]
+            my = cy - p[1]
+            cc = (mx * mx + my * my) - rad * rad
+            b = mx * dx + my * dy
+            disc = b * b - cc
+            if not disc >= 0.0:
+                continue
+            sq = math.sqrt(disc)
+            t = b - sq
+            if t < 0.0:
+                t = b + sq
+            if t >= 0.0 and t < best:
+                best = t
+                hit = j
+        for q, verts in enumerate(polys_world):
+            nv = len(verts)
+            for k in range(nv):
+                Ax, Ay = verts[k]
+                Bx, By = verts[(k + 1) % nv]
+                ax = Ax - p[0]
+                ay = Ay - p[1]
+                ex = Bx - Ax
+                ey = By - Ay
+                nt = ax * ey - ay * ex
+                den = dx * ey - dy * ex
+                ns = ax * dy - ay * dx
+                if den > 0.0:
+                    ok = 0.0 <= ns <= den
+                elif den < 0.0:
+                    ok = den <= ns <= 0.0
+                else:
+                    ok = False
+                if not ok:
+                    continue
+                t = nt / den
+                if t >= 0.0 and t < best:
+                    best = t
+                    hit = len(circles) + q
+        out_r.append(best)
+        out_i.append(hit)
+    return np.array(out_r), np.array(out_i, dtype=np.int32)

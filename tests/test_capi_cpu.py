@@ -1,0 +1,89 @@
+"""The C-ABI library loads on a machine without a GPU, exports exactly what
+include/auvsim.h declares, and fails loudly (never falls back) when asked to
+compute without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gym_auv_amd import _lib, params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "auvsim.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(auv_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_functions() == sorted(_lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in _declared_functions():
+        assert hasattr(lib, name), f"libauvsim.so does not export {name}"
+    assert b"gfx950" in lib.auv_version()
+
+
+def test_config_struct_layout_matches_header():
+    # 8 int32 + 7 double + risk[3] + reward[4] + model[16]
+    assert C.sizeof(_lib.AuvConfig) == 8 * 4 + (7 + 3 + 4 + 16) * 8
+
+
+def test_buffer_enum_matches_header():
+    text = open(os.path.join(ROOT, "include", "auvsim.h")).read()
+    enum = dict(re.findall(r"(AUV_BUF_[A-Z_]+)\s*=\s*(\d+)", text))
+    for name, idx in _lib.BUFFER_NAMES.items():
+        assert int(enum["AUV_BUF_" + name.upper()]) == idx
+    assert int(enum["AUV_BUF_COUNT"]) == _lib.BUF_COUNT
+
+
+def test_create_rejects_bad_arguments_before_touching_a_device(lib):
+    h = C.c_void_p()
+    cfg = _lib.AuvConfig()
+    cfg.abi_version = 999
+    assert lib.auv_create(C.byref(cfg), 0, C.byref(h)) == -1
+    assert b"abi_version" in lib.auv_last_error(None)
+    cfg.abi_version = _lib.ABI_VERSION
+    cfg.n_envs = 0
+    cfg.n_rays = 180
+    assert lib.auv_create(C.byref(cfg), 0, C.byref(h)) == -1
+    assert not h.value
+
+
+def test_no_gpu_means_error_not_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device path cannot be exercised")
+    from gym_auv_amd.sim import AuvSim
+
+    with pytest.raises(_lib.AuvError) as ei:
+        AuvSim(params.make_config(4, 1, 0))
+    assert ei.value.code == -2
+
+
+def test_dlpack_capsule_fields():
+    from gym_auv_amd import dlpack
+
+    cap = dlpack.to_capsule(0x1000, (3, 1, 180), _lib.F32, 0)
+    get = C.pythonapi.PyCapsule_GetPointer
+    get.restype = C.c_void_p
+    get.argtypes = [C.py_object, C.c_char_p]
+    mt = C.cast(get(cap, b"dltensor"), C.POINTER(dlpack.DLManagedTensor)).contents
+    t = mt.dl_tensor
+    assert t.data == 0x1000 and t.ndim == 3 and [t.shape[i] for i in range(3)] == [3, 1, 180]
+    assert (t.dtype.code, t.dtype.bits, t.dtype.lanes) == (2, 32, 1)
+    assert t.device.device_type == dlpack.kDLROCM
+    mt.deleter(C.pointer(mt))
+
+
+def test_model_constants_invert_the_mass_matrix():
+    mp = params.model_constants()
+    M = np.array([[mp[5], 0, 0], [0, mp[6], mp[7]], [0, mp[7], 2.76]])
+    Minv = np.array([[mp[0], 0, 0], [0, mp[1], mp[2]], [0, mp[3], mp[4]]])
+    assert np.allclose(M @ Minv, np.eye(3), atol=1e-14)

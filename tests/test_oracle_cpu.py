@@ -1,0 +1,186 @@
+"""CPU checks of the oracle itself: the contract's elementary functions, the
+vectorised forms against the scalar restatement, and hand-computed geometric
+known answers.  (The simulator is absent from the reference checkout, so no
+reference fixture exists for these; the consumer-side fixtures are tested in
+test_consumers_cpu.py.)"""
+import numpy as np
+
+from gym_auv_amd import params, scenarios
+from oracle import auv_oracle as O
+from tests.helpers import make_oracle
+
+
+def test_sincos_accuracy():
+    x = np.random.default_rng(0).uniform(-20, 20, 200000)
+    s, c = O.sincos(x)
+    assert np.abs(s - np.sin(x)).max() < 3e-16
+    assert np.abs(c - np.cos(x)).max() < 3e-16
+    s0, c0 = O.sincos(np.array([0.0]))
+    assert s0[0] == 0.0 and c0[0] == 1.0
+
+
+def test_atan2_accuracy_and_quadrants():
+    rng = np.random.default_rng(1)
+    y = rng.normal(size=200000)
+    x = rng.normal(size=200000)
+    assert np.abs(O.atan2(y, x) - np.arctan2(y, x)).max() < 1e-15
+    got = O.atan2(np.array([0.0, 1.0, -1.0, 0.0, 0.0]), np.array([0.0, 0.0, 0.0, 1.0, -1.0]))
+    assert np.allclose(got, [0.0, np.pi / 2, -np.pi / 2, 0.0, np.pi], atol=1e-15)
+
+
+def test_wrap_angle_range():
+    a = np.random.default_rng(2).uniform(-50, 50, 10000)
+    w = O.wrap_angle(a)
+    assert (w >= -np.pi - 1e-15).all() and (w < np.pi).all()
+    assert np.abs(np.sin(w) - np.sin(a)).max() < 1e-13
+
+
+def test_ray_table_full_circle():
+    t = params.ray_table(180)
+    assert t.shape == (180, 2)
+    assert np.allclose(t[-1], [-1.0, 0.0], atol=1e-15)          # last ray dead astern
+    assert np.allclose(t[89], [1.0, 0.0], atol=1e-15)           # ray 89 dead ahead
+    assert np.allclose(np.hypot(t[:, 0], t[:, 1]), 1.0)
+
+
+def _one_env(circles=(), polys=(), psi=0.0, R=180, NV=4):
+    C, P = len(circles), len(polys)
+    cfg = params.make_config(1, C, P, NV, n_rays=R)
+    circ = np.zeros((1, C, 5))
+    for j, c in enumerate(circles):
+        circ[0, j, :3] = c
+    pose = np.zeros((1, P, 6))
+    pose[:, :, 2] = 1.0
+    verts = np.zeros((1, P, NV, 2))
+    nv = np.zeros((1, P), dtype=np.int32)
+    for q, v in enumerate(polys):
+        if len(v):
+            verts[0, q, :len(v)] = v
+        nv[0, q] = len(v)
+    init = np.zeros((6, 1))
+    init[2] = psi
+    path = np.zeros((1, 6))
+    path[0, 3] = 1.0
+    path[0, 5] = 800.0
+    scene = dict(circles=circ, poly_pose=pose, poly_verts=verts, poly_nv=nv,
+                 poly_heading=np.zeros((1, P)), init_state=init, path=path)
+    env = make_oracle(cfg, scene)
+    env.reset(init)
+    return env
+
+
+def test_lidar_known_answers_circle():
+    # circle of radius 10 centred 50 m dead ahead: the ahead ray (index 89) reads 40
+    env = _one_env(circles=[(50.0, 0.0, 10.0)])
+    assert abs(env.ranges[0, 89] - 40.0) < 1e-12 and env.hit[0, 89] == 0
+    assert env.ranges[0, 179] == 150.0 and env.hit[0, 179] == -1
+    # rays within asin(10/50) = 11.5 deg of ahead hit, others do not
+    ang = -np.pi + (np.arange(180) + 1) * (2 * np.pi / 180)
+    expect = np.abs(ang) < np.arcsin(0.2)
+    assert np.array_equal(env.hit[0] == 0, expect)
+    # heading rotates the scan: facing +y, the circle is 90 deg to starboard (ray 44)
+    env = _one_env(circles=[(50.0, 0.0, 10.0)], psi=np.pi / 2)
+    assert abs(env.ranges[0, 44] - 40.0) < 1e-9
+
+
+def test_lidar_from_inside_and_out_of_range():
+    env = _one_env(circles=[(0.0, 0.0, 20.0)])          # vessel at the centre
+    assert np.allclose(env.ranges[0], 20.0) and (env.hit[0] == 0).all()
+    assert env.collision[0] == 1 and env.min_dist[0] < 0
+    env = _one_env(circles=[(300.0, 0.0, 10.0)])
+    assert (env.hit[0] == -1).all() and (env.ranges[0] == 150.0).all()
+    assert env.collision[0] == 0
+
+
+def test_lidar_known_answers_polygon_and_ties():
+    sq = [(40.0, -10.0), (60.0, -10.0), (60.0, 10.0), (40.0, 10.0)]
+    env = _one_env(polys=[sq])
+    assert abs(env.ranges[0, 89] - 40.0) < 1e-12 and env.hit[0, 89] == 0
+    assert abs(env.obst_dist[0, 0] - (40.0 - 2.0)) < 1e-12
+    # identical circle listed twice: the lower id wins the tie
+    env = _one_env(circles=[(50.0, 0.0, 10.0), (50.0, 0.0, 10.0)])
+    assert set(np.unique(env.hit[0])) == {-1, 0}
+    # absent slots (radius <= 0, nv == 0) never hit and have infinite distance
+    env = _one_env(circles=[(50.0, 0.0, 0.0)], polys=[[]])
+    assert (env.hit[0] == -1).all() and np.isinf(env.obst_dist[0]).all()
+    assert env.min_idx[0] == -1
+
+
+def test_polygon_inside_is_negative_distance():
+    sq = [(-10.0, -10.0), (10.0, -10.0), (10.0, 10.0), (-10.0, 10.0)]
+    env = _one_env(polys=[sq])
+    assert abs(env.obst_dist[0, 0] - (-10.0 - 2.0)) < 1e-12
+    assert env.collision[0] == 1
+
+
+def test_vectorised_lidar_equals_scalar_form():
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=6)
+    env = make_oracle(cfg, scene)
+    env.reset(scene["init_state"])
+    acts = scenarios.random_actions(6, 5, seed=3)
+    for k in range(5):
+        env.step(acts[k])
+    wx, wy = O.polygon_world_vertices(env.poly_pose, env.poly_verts)
+    for e in range(6):
+        polys = [[(wx[e, p, k], wy[e, p, k]) for k in range(env.poly_nv[e, p])]
+                 for p in range(cfg["n_polys"])]
+        circ = [tuple(env.circles[e, j, :3]) for j in range(cfg["n_circles"])]
+        r, i = O.lidar_scalar((env.state[0, e], env.state[1, e]), env.state[2, e], circ, polys,
+                              env.ray_dirs, cfg["sensor_range"])
+        assert np.array_equal(r, env.ranges[e]) and np.array_equal(i, env.hit[e])
+
+
+def test_dynamics_settles_and_turns():
+    cfg = params.make_config(2, 0, 0)
+    s = np.zeros((6, 2))
+    a = np.array([[1.0, 1.0], [0.0, 0.5]])
+    for _ in range(400):
+        s = O.step_dynamics(s, a, cfg)
+    # full thrust, no rudder: steady surge = root of Xu*u + Xuu*u|u| = thrust_max
+    u = s[3, 0]
+    assert abs(2.0 * u + 1.32742 * u * u - 2.0) < 1e-9
+    assert abs(s[1, 0]) < 1e-12 and abs(s[2, 0]) < 1e-12
+    # rudder makes it turn, heading stays wrapped
+    assert abs(s[5, 1]) > 1e-3 and -np.pi <= s[2, 1] < np.pi
+
+
+def test_rkf45_is_fifth_order():
+    cfg = params.make_config(1, 0, 0)
+    a = np.array([[0.7], [0.3]])
+    s0 = np.array([[0.0], [0.0], [0.2], [0.5], [0.05], [0.02]])
+
+    def run(dt, n):
+        c = dict(cfg, dt=dt)
+        s = s0.copy()
+        for _ in range(n):
+            s = O.step_dynamics(s, a, c)
+        return s
+    ref = run(0.0625, 64)
+    e1 = np.abs(run(1.0, 4) - ref)[[0, 1, 3, 4, 5]].max()
+    e2 = np.abs(run(0.5, 8) - ref)[[0, 1, 3, 4, 5]].max()
+    assert e2 < e1 / 16.0      # at least 4th-order shrink per halving
+
+
+def test_observation_layout_matches_consumer_contract():
+    cfg, scene = scenarios.make_workload("cfg2_4096_static", n_envs=5)
+    env = make_oracle(cfg, scene)
+    env.reset(scene["init_state"])
+    assert env.perception.shape == (5, 1, 180) and env.perception.dtype == np.float32
+    assert env.navigation.shape == (5, 1, 6) and env.navigation.dtype == np.float32
+    assert np.array_equal(env.perception[:, 0], (1.0 - env.ranges / 150.0).astype(np.float32))
+    assert env.meta.shape == (5, 16, 5) and env.risk.shape == (5, 16)
+    assert ((env.risk >= 0) & (env.risk < 1)).all()
+
+
+def test_masked_reset_restores_obstacles():
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=4)
+    env = make_oracle(cfg, scene)
+    env.reset(scene["init_state"])
+    p0 = env.poly_pose.copy()
+    for k in range(3):
+        env.step(scenarios.random_actions(4, 1, seed=k)[0])
+    assert not np.array_equal(env.poly_pose, p0)
+    env.reset(scene["init_state"], mask=np.array([1, 0, 0, 1]))
+    assert np.array_equal(env.poly_pose[[0, 3]], p0[[0, 3]])
+    assert not np.array_equal(env.poly_pose[1], p0[1])
+    assert list(env.t_step) == [0, 3, 3, 0]
