@@ -58,8 +58,8 @@ def main():
     ap.add_argument("--workload", default="cfg3_65536_moving")
     ap.add_argument("--envs", type=int, default=None, help="override vessels per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-envs", type=int, default=1024)
-    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-envs", type=int, default=4096)
+    ap.add_argument("--cpu-steps", type=int, default=60)
     args = ap.parse_args()
 
     import torch

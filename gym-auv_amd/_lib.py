@@ -37,7 +37,7 @@ BUFFER_NAMES = {
 EXPORTS = (
     "auv_version", "auv_last_error", "auv_create", "auv_destroy", "auv_set_rays",
     "auv_set_scene", "auv_reset", "auv_step", "auv_step_host", "auv_sense",
-    "auv_get_buffer", "auv_read_buffer", "auv_sync", "auv_profile_enable",
+    "auv_get_buffer", "auv_read_buffer", "auv_dlpack", "auv_sync", "auv_profile_enable",
     "auv_profile_read",
 )
 
@@ -72,6 +72,13 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; a process must run
+    # ONE HIP runtime, or the second one finds no GPU and device pointers are
+    # not shared.  Importing torch first makes its runtime the one that
+    # libauvsim's NEEDED libamdhip64.so.7 resolves to (same soname), so the
+    # DLPack views and torch streams belong to the runtime the kernels use.
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     dp = C.POINTER(C.c_double)
@@ -100,6 +107,8 @@ def load():
                                    C.POINTER(i32)]
     lib.auv_read_buffer.restype = C.c_int
     lib.auv_read_buffer.argtypes = [vp, C.c_int, vp, i64, vp]
+    lib.auv_dlpack.restype = vp
+    lib.auv_dlpack.argtypes = [vp, C.c_int]
     lib.auv_sync.restype = C.c_int
     lib.auv_sync.argtypes = [vp, vp]
     lib.auv_profile_enable.restype = C.c_int

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -47,7 +48,6 @@ struct auv_sim {
     auv_config cfg;
     Dims d;
     int device = 0;
-    hipStream_t stream = nullptr;
     BufDesc buf[AUV_BUF_COUNT];
     // scene / auxiliary device memory not lent out
     double* poly_verts = nullptr;
@@ -105,14 +105,14 @@ int alloc_buf(auv_sim* h, int which, int32_t dtype, std::initializer_list<int64_
     b.bytes = n * dtype_size(dtype);
     // zero-sized slots (e.g. no polygons) still get a valid, distinct pointer
     HIP_TRY(h, hipMalloc(&b.ptr, b.bytes ? b.bytes : 256));
-    HIP_TRY(h, hipMemsetAsync(b.ptr, 0, b.bytes ? b.bytes : 256, h->stream));
+    HIP_TRY(h, hipMemset(b.ptr, 0, b.bytes ? b.bytes : 256));
     return AUV_OK;
 }
 
 template <typename T>
 int alloc_raw(auv_sim* h, T** p, size_t n) {
     HIP_TRY(h, hipMalloc((void**)p, n ? n * sizeof(T) : 256));
-    HIP_TRY(h, hipMemsetAsync(*p, 0, n ? n * sizeof(T) : 256, h->stream));
+    HIP_TRY(h, hipMemset(*p, 0, n ? n * sizeof(T) : 256));
     return AUV_OK;
 }
 
@@ -121,7 +121,8 @@ T* bp(auv_sim* h, int which) {
     return static_cast<T*>(h->buf[which].ptr);
 }
 
-hipStream_t pick(auv_sim* h, void* stream) { return stream ? (hipStream_t)stream : h->stream; }
+// NULL is HIP's default (null) stream, exactly as in the HIP API itself
+hipStream_t pick(auv_sim*, void* stream) { return (hipStream_t)stream; }
 
 void choose_geometry(auv_sim* h) {
     const Dims& d = h->d;
@@ -325,10 +326,6 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     }
     int rc = AUV_OK;
     auto chk = [&](int r) { if (rc == AUV_OK && r != AUV_OK) rc = r; };
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete h;
-        return fail(nullptr, AUV_ERR_DEVICE, "hipStreamCreate failed");
-    }
     const int64_t V = d.V, R = d.R, C = d.C, P = d.P, NV = d.NV, O = d.O;
     chk(alloc_buf(h, AUV_BUF_STATE, AUV_F64, {6, V}));
     chk(alloc_buf(h, AUV_BUF_ACTION, AUV_F64, {2, V}));
@@ -360,7 +357,7 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     chk(alloc_raw(h, &h->circles0, (size_t)V * C * 5));
     chk(alloc_raw(h, &h->poly_pose0, (size_t)V * P * 6));
     chk(alloc_raw(h, &h->mask_stage, (size_t)V));
-    if (rc == AUV_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = AUV_ERR_DEVICE;
+    if (rc == AUV_OK && hipDeviceSynchronize() != hipSuccess) rc = AUV_ERR_DEVICE;
     if (rc != AUV_OK) {
         g_create_error = "auv_create: " + h->err;
         auv_destroy(h);
@@ -383,7 +380,7 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
 void auv_destroy(auv_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipDeviceSynchronize();
     for (auto& ev : h->events) (void)hipEventDestroy(ev);
     for (auto& b : h->buf)
         if (b.ptr) (void)hipFree(b.ptr);
@@ -391,7 +388,6 @@ void auv_destroy(auv_handle h) {
                    h->circles0, h->poly_pose0};
     for (void* p : raw)
         if (p) (void)hipFree(p);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -536,6 +532,59 @@ int auv_sync(auv_handle h, void* stream) {
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(pick(h, stream)));
     return AUV_OK;
+}
+
+// DLPack (legacy DLManagedTensor ABI) -------------------------------------
+namespace {
+struct DlDevice { int32_t device_type; int32_t device_id; };
+struct DlDataType { uint8_t code; uint8_t bits; uint16_t lanes; };
+struct DlTensor {
+    void* data;
+    DlDevice device;
+    int32_t ndim;
+    DlDataType dtype;
+    int64_t* shape;
+    int64_t* strides;
+    uint64_t byte_offset;
+};
+struct DlManagedTensor {
+    DlTensor dl_tensor;
+    void* manager_ctx;
+    void (*deleter)(DlManagedTensor*);
+};
+struct DlExport {
+    DlManagedTensor mt;
+    int64_t shape[4];
+};
+void dl_delete(DlManagedTensor* mt) { delete reinterpret_cast<DlExport*>(mt); }
+}  // namespace
+
+void* auv_dlpack(auv_handle h, int which) {
+    if (!h) return nullptr;
+    if (which < 0 || which >= AUV_BUF_COUNT) {
+        fail(h, AUV_ERR_ARG, "auv_dlpack: unknown buffer %d", which);
+        return nullptr;
+    }
+    const BufDesc& b = h->buf[which];
+    DlExport* e = new DlExport();
+    static_assert(offsetof(DlExport, mt) == 0, "managed tensor must lead the export record");
+    for (int i = 0; i < 4; ++i) e->shape[i] = b.shape[i];
+    e->mt.dl_tensor.data = b.ptr;
+    e->mt.dl_tensor.device = {10 /* kDLROCM */, h->device};
+    e->mt.dl_tensor.ndim = b.ndim;
+    switch (b.dtype) {
+        case AUV_F64: e->mt.dl_tensor.dtype = {2, 64, 1}; break;
+        case AUV_F32: e->mt.dl_tensor.dtype = {2, 32, 1}; break;
+        case AUV_I32: e->mt.dl_tensor.dtype = {0, 32, 1}; break;
+        case AUV_I64: e->mt.dl_tensor.dtype = {0, 64, 1}; break;
+        default: e->mt.dl_tensor.dtype = {1, 8, 1}; break;
+    }
+    e->mt.dl_tensor.shape = e->shape;
+    e->mt.dl_tensor.strides = nullptr;  // dense row-major
+    e->mt.dl_tensor.byte_offset = 0;
+    e->mt.manager_ctx = nullptr;
+    e->mt.deleter = dl_delete;
+    return &e->mt;
 }
 
 int auv_profile_enable(auv_handle h, int32_t on) {

@@ -2,7 +2,9 @@
 envs on one GPU)."""
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -33,6 +35,17 @@ def _stream_handle(stream):
     return C.c_void_p(stream.cuda_stream)
 
 
+_live = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    # handles must be destroyed while the HIP runtime is still up; at
+    # interpreter exit __del__ would run after the runtime's own teardown
+    for sim in list(_live):
+        sim.close()
+
+
 class AuvSim:
     def __init__(self, cfg: dict, device: int = 0, ray_dirs=None):
         self._lib = _lib.load()
@@ -59,6 +72,7 @@ class AuvSim:
         self.V, self.R = int(cfg["n_envs"]), int(cfg["n_rays"])
         self.C, self.P, self.NV = int(cfg["n_circles"]), int(cfg["n_polys"]), int(cfg["n_verts"])
         self.O = self.C + self.P
+        _live.add(self)
         self.set_rays(ray_table(self.R) if ray_dirs is None else ray_dirs)
 
     # -- lifetime ---------------------------------------------------------
@@ -145,8 +159,11 @@ class AuvSim:
 
     def tensor(self, name):
         """torch tensor aliasing a device buffer through DLPack (zero-copy)."""
-        ptr, shape, dt = self.buffer(name)
-        return dlpack.to_torch(ptr, shape, dt, self.device, owner=self)
+        which = _lib.BUFFER_NAMES[name] if isinstance(name, str) else int(name)
+        mt = self._lib.auv_dlpack(self._h, which)
+        if not mt:
+            raise _lib.AuvError(-1, self._lib.auv_last_error(self._h).decode())
+        return dlpack.to_torch(mt)
 
     # -- profiling ----------------------------------------------------------
     def profile(self, on: bool):

@@ -20,8 +20,9 @@
  * handle per GPU per process; calls on one handle must be serialised by the
  * caller.  Device buffers are owned by the library and lent out by
  * auv_get_buffer() for the life of the handle.  Kernels are enqueued on the
- * stream given to the call (NULL = the handle's own stream), so a PyTorch
- * caller orders against them by passing its current stream.
+ * hipStream_t given to the call (NULL = HIP's default stream, as in the HIP
+ * API), so a PyTorch caller orders against them by passing its current
+ * stream.
  */
 #ifndef AUVSIM_H
 #define AUVSIM_H
@@ -147,7 +148,14 @@ int auv_get_buffer(auv_handle h, int which, void** dev_ptr, int64_t* shape,
 /* Copy a buffer to host memory (synchronises `stream`). */
 int auv_read_buffer(auv_handle h, int which, void* host_dst, int64_t nbytes, void* stream);
 
-/* Block until all work enqueued on `stream` (NULL = the handle's) is done. */
+/* Borrow a device buffer as a DLPack DLManagedTensor* (device type kDLROCM),
+ * malloc'ed by the library; the consumer's call of its deleter frees the
+ * record, never the buffer.  A Python caller wraps the pointer in a PyCapsule
+ * named "dltensor" for torch.from_dlpack (consumer: the tensors that
+ * radarCNN.py:275 feeds to the CNN).  NULL on error. */
+void* auv_dlpack(auv_handle h, int which);
+
+/* Block until all work enqueued on `stream` is done. */
 int auv_sync(auv_handle h, void* stream);
 
 /* Per-kernel device timing.  While enabled, auv_step brackets each kernel

@@ -67,19 +67,13 @@ def test_no_gpu_means_error_not_fallback():
     assert ei.value.code == -2
 
 
-def test_dlpack_capsule_fields():
+def test_dlpack_record_layout():
+    # the mirror of the C record the consumer reads: 48-byte DLTensor, then ctx + deleter
     from gym_auv_amd import dlpack
 
-    cap = dlpack.to_capsule(0x1000, (3, 1, 180), _lib.F32, 0)
-    get = C.pythonapi.PyCapsule_GetPointer
-    get.restype = C.c_void_p
-    get.argtypes = [C.py_object, C.c_char_p]
-    mt = C.cast(get(cap, b"dltensor"), C.POINTER(dlpack.DLManagedTensor)).contents
-    t = mt.dl_tensor
-    assert t.data == 0x1000 and t.ndim == 3 and [t.shape[i] for i in range(3)] == [3, 1, 180]
-    assert (t.dtype.code, t.dtype.bits, t.dtype.lanes) == (2, 32, 1)
-    assert t.device.device_type == dlpack.kDLROCM
-    mt.deleter(C.pointer(mt))
+    assert C.sizeof(dlpack.DLTensor) == 48
+    assert C.sizeof(dlpack.DLManagedTensor) == 64
+    assert dlpack.DLTensor.shape.offset == 24 and dlpack.DLTensor.byte_offset.offset == 40
 
 
 def test_model_constants_invert_the_mass_matrix():
