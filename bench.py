@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg3_65536_moving")
     ap.add_argument("--envs", type=int, default=None, help="override vessels per GPU")
+    ap.add_argument("--lidar-mode", type=int, default=0, help="0 rasterising (default), 1 all pairs")
+    ap.add_argument("--tile", type=int, default=0, help="envs per LiDAR workgroup, 0 = auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=60)
@@ -65,7 +67,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from gym_auv_amd import scenarios
+    from gym_auv_amd import _lib, scenarios
     from gym_auv_amd.sim import AuvSim
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,6 +84,9 @@ def main():
     cfg, scene = scenarios.make_workload(args.workload, n_envs=args.envs, rank=rank)
     V, R, C, P, NV = cfg["n_envs"], cfg["n_rays"], cfg["n_circles"], cfg["n_polys"], cfg["n_verts"]
     sim = AuvSim(cfg, device=local_rank)
+    sim.set_option(_lib.OPT_LIDAR_MODE, args.lidar_mode)
+    if args.tile:
+        sim.set_option(_lib.OPT_RASTER_TILE, args.tile)
     sim.set_scene(scene)
     stream = torch.cuda.current_stream(dev)
     sim.reset(scene["init_state"], stream=stream)
@@ -100,6 +105,13 @@ def main():
     for k in range(args.warmup):
         sim.step_device(ptrs[k % n_act], stream=stream)
     sync_all()
+    # an un-instrumented rehearsal of the same K steps: tells how much the
+    # per-kernel HIP events cost (reported as ms_per_step_no_events)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        sim.step_device(ptrs[k % n_act], stream=stream)
+    sync_all()
+    plain_elapsed = time.perf_counter() - t0
     sim.profile(True)
     sim.profile_read()
     t0 = time.perf_counter()
@@ -132,7 +144,9 @@ def main():
             "metric": "vessel_env_steps_per_sec", "value": env_steps / elapsed, "unit": "env-steps/s",
             "rays_per_sec": env_steps * R / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_no_events": plain_elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "vessels_per_gpu": V, "rays": R, "circles": C,
                        "polygons": P, "edges_per_polygon": NV, "sensor_range_m": cfg["sensor_range"],

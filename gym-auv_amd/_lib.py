@@ -33,11 +33,16 @@ BUFFER_NAMES = {
     "reward": BUF_REWARD,
 }
 
+# auv_option
+OPT_LIDAR_MODE, OPT_RASTER_TILE = 0, 1
+LIDAR_RASTER, LIDAR_ALL_PAIRS = 0, 1
+
 # every symbol include/auvsim.h declares
 EXPORTS = (
     "auv_version", "auv_last_error", "auv_create", "auv_destroy", "auv_set_rays",
     "auv_set_scene", "auv_reset", "auv_step", "auv_step_host", "auv_sense",
-    "auv_get_buffer", "auv_read_buffer", "auv_dlpack", "auv_sync", "auv_profile_enable",
+    "auv_get_buffer", "auv_read_buffer", "auv_dlpack", "auv_sync", "auv_set_option",
+    "auv_profile_enable",
     "auv_profile_read",
 )
 
@@ -109,6 +114,8 @@ def load():
     lib.auv_read_buffer.argtypes = [vp, C.c_int, vp, i64, vp]
     lib.auv_dlpack.restype = vp
     lib.auv_dlpack.argtypes = [vp, C.c_int]
+    lib.auv_set_option.restype = C.c_int
+    lib.auv_set_option.argtypes = [vp, i32, i32]
     lib.auv_sync.restype = C.c_int
     lib.auv_sync.argtypes = [vp, vp]
     lib.auv_profile_enable.restype = C.c_int

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "auv_kernels.hpp"
+#include "auv_lidar_raster.hpp"
 
 using namespace auv;
 
@@ -40,6 +41,7 @@ size_t dtype_size(int32_t dt) {
     return 0;
 }
 
+constexpr size_t kLdsMax = 160u * 1024u;  // LDS of one gfx950 CU; a workgroup may claim all of it
 constexpr int kProfRing = 256;  // steps whose events are kept before a forced drain
 
 }  // namespace
@@ -63,6 +65,9 @@ struct auv_sim {
     // launch geometry
     int lidar_te = 1, lidar_block = 256, enc_eb = 1;
     size_t lidar_lds = 0, enc_lds = 0;
+    int lidar_mode = AUV_LIDAR_RASTER;
+    int raster_te = 1, raster_cap = 2048;
+    size_t raster_lds = 0;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;  // kProfRing * 4
@@ -124,6 +129,29 @@ T* bp(auv_sim* h, int which) {
 // NULL is HIP's default (null) stream, exactly as in the HIP API itself
 hipStream_t pick(auv_sim*, void* stream) { return (hipStream_t)stream; }
 
+// Tile of the rasterising LiDAR: `want` envs per workgroup, or (want <= 0) as
+// many as keep the LDS image under ~40 KiB (>= 3-4 workgroups per CU) while
+// the grid still has >= 1024 workgroups.  The pair list holds 2048 slots, or
+// fewer when one env's primitives leave less room under the 64 KiB window.
+void set_raster_tile(auv_sim* h, int want) {
+    const Dims& d = h->d;
+    const int S = d.P * d.NV;
+    int cap = 2048;
+    while (cap > 256 && raster_layout(1, d.R, d.C, S, cap).total > kLdsMax) cap >>= 1;
+    int te = want;
+    if (te <= 0) {
+        te = 16;
+        while (te > 1 && raster_layout(te, d.R, d.C, S, cap).total > 40u * 1024u) te >>= 1;
+        while (te > 1 && (d.V + te - 1) / te < 1024) te >>= 1;
+    }
+    while (te > 1 && raster_layout(te, d.R, d.C, S, cap).total > kLdsMax) te >>= 1;
+    h->raster_te = te;
+    h->raster_cap = cap;
+    h->raster_lds = raster_layout(te, d.R, d.C, S, cap).total;
+    // the pair list packs (primitive, ray offset) into 16 bits each
+    if ((long long)te * (d.C + S) > 65535 || d.R > 65535) h->raster_lds = (size_t)1 << 30;
+}
+
 void choose_geometry(auv_sim* h) {
     const Dims& d = h->d;
     const int S = d.P * d.NV;
@@ -141,6 +169,8 @@ void choose_geometry(auv_sim* h) {
     const long long rays = (long long)te * d.R;
     h->lidar_block = (rays % 192 == 0 && rays % 256 != 0) ? 192 : 256;
     if (rays < 256) h->lidar_block = (int)(((rays + 63) / 64) * 64);
+    // rasterising LiDAR: tile by its own (larger) LDS image, 36 KiB budget
+    set_raster_tile(h, 0);
     // encounter: one thread per (env, obstacle), whole envs per block
     const int O = d.O > 0 ? d.O : 1;
     int eb = 256 / O;
@@ -206,8 +236,17 @@ int launch_sense(auv_sim* h, hipStream_t st, hipEvent_t* ev, int is_step) {
     la.hit = bp<int32_t>(h, AUV_BUF_HIT);
     la.perception = bp<float>(h, AUV_BUF_PERCEPTION);
     la.sensor_range = h->cfg.sensor_range;
-    const int lid_blocks = (d.V + h->lidar_te - 1) / h->lidar_te;
-    hipLaunchKernelGGL(k_lidar, dim3(lid_blocks), dim3(h->lidar_block), h->lidar_lds, st, la);
+    if (h->lidar_mode == AUV_LIDAR_ALL_PAIRS) {
+        const int lid_blocks = (d.V + h->lidar_te - 1) / h->lidar_te;
+        hipLaunchKernelGGL(k_lidar, dim3(lid_blocks), dim3(h->lidar_block), h->lidar_lds, st, la);
+    } else {
+        RasterArgs ra;
+        ra.l = la;
+        ra.l.TE = h->raster_te;
+        ra.cap = h->raster_cap;
+        const int lid_blocks = (d.V + h->raster_te - 1) / h->raster_te;
+        hipLaunchKernelGGL(k_lidar_raster, dim3(lid_blocks), dim3(256), h->raster_lds, st, ra);
+    }
     HIP_TRY(h, hipGetLastError());
     if (ev) HIP_TRY(h, hipEventRecord(ev[3], st));
     return AUV_OK;
@@ -317,10 +356,19 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     d.NV = cfg->n_polys > 0 ? cfg->n_verts : 1;
     d.O = d.C + d.P;
     choose_geometry(h);
-    if (h->lidar_lds > 64 * 1024) {
+    // dynamic LDS beyond the 64 KiB default window has to be granted per kernel
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lidar_raster), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kLdsMax) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_lidar), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kLdsMax) != hipSuccess) {
+        delete h;
+        return fail(nullptr, AUV_ERR_DEVICE, "auv_create: cannot raise the dynamic LDS limit to %zu", kLdsMax);
+    }
+    if (h->raster_lds > kLdsMax) h->lidar_mode = AUV_LIDAR_ALL_PAIRS;  // image too big: fall back to the smaller one
+    if (h->lidar_lds > kLdsMax) {
         // one env's primitives must fit the default dynamic-LDS window
         std::string msg = "auv_create: one env needs " + std::to_string(h->lidar_lds) +
-                          " B of LDS for its obstacle primitives (limit 65536)";
+                          " B of LDS for its obstacle primitives (limit 163840)";
         delete h;
         return fail(nullptr, AUV_ERR_ARG, "%s", msg.c_str());
     }
@@ -585,6 +633,26 @@ void* auv_dlpack(auv_handle h, int which) {
     e->mt.manager_ctx = nullptr;
     e->mt.deleter = dl_delete;
     return &e->mt;
+}
+
+int auv_set_option(auv_handle h, int32_t key, int32_t value) {
+    if (!h) return AUV_ERR_ARG;
+    switch (key) {
+        case AUV_OPT_LIDAR_MODE:
+            if (value != AUV_LIDAR_RASTER && value != AUV_LIDAR_ALL_PAIRS)
+                return fail(h, AUV_ERR_ARG, "auv_set_option: unknown LiDAR mode %d", value);
+            if (value == AUV_LIDAR_RASTER && h->raster_lds > kLdsMax)
+                return fail(h, AUV_ERR_ARG, "auv_set_option: rasterising LiDAR needs %zu B of LDS per env (limit 163840)",
+                            h->raster_lds);
+            h->lidar_mode = value;
+            return AUV_OK;
+        case AUV_OPT_RASTER_TILE:
+            if (value < 0 || value > 64)
+                return fail(h, AUV_ERR_ARG, "auv_set_option: envs per workgroup must be 0 (auto) or 1..64");
+            set_raster_tile(h, value);
+            return AUV_OK;
+    }
+    return fail(h, AUV_ERR_ARG, "auv_set_option: unknown key %d", key);
 }
 
 int auv_profile_enable(auv_handle h, int32_t on) {

@@ -165,6 +165,9 @@ class AuvSim:
             raise _lib.AuvError(-1, self._lib.auv_last_error(self._h).decode())
         return dlpack.to_torch(mt)
 
+    def set_option(self, key: int, value: int):
+        self._check(self._lib.auv_set_option(self._h, int(key), int(value)))
+
     # -- profiling ----------------------------------------------------------
     def profile(self, on: bool):
         self._check(self._lib.auv_profile_enable(self._h, 1 if on else 0))

@@ -99,6 +99,16 @@ typedef enum auv_buffer {
     AUV_BUF_COUNT = 21
 } auv_buffer;
 
+/* Tunables (auv_set_option).  Both LiDAR kernels produce identical bits; the
+ * all-pairs one tests every ray against every primitive and exists as the
+ * cross-check of the rasterising default. */
+typedef enum auv_option {
+    AUV_OPT_LIDAR_MODE = 0,   /* AUV_LIDAR_RASTER (default) | AUV_LIDAR_ALL_PAIRS */
+    AUV_OPT_RASTER_TILE = 1   /* envs per workgroup of the rasterising kernel; 0 = auto */
+} auv_option;
+#define AUV_LIDAR_RASTER 0
+#define AUV_LIDAR_ALL_PAIRS 1
+
 /* Library build information: "libauvsim <abi> gfx950 ...". */
 const char* auv_version(void);
 
@@ -157,6 +167,9 @@ void* auv_dlpack(auv_handle h, int which);
 
 /* Block until all work enqueued on `stream` is done. */
 int auv_sync(auv_handle h, void* stream);
+
+/* Set a tunable; takes effect from the next reset/step/sense. */
+int auv_set_option(auv_handle h, int32_t key, int32_t value);
 
 /* Per-kernel device timing.  While enabled, auv_step brackets each kernel
  * with HIP events on the launch stream.  auv_profile_read synchronises and

@@ -25,8 +25,12 @@ def make_oracle(cfg, scene):
     return env
 
 
-def make_sim(cfg, scene, device=0):
+def make_sim(cfg, scene, device=0, lidar_mode=None):
     sim = AuvSim(cfg, device=device)
+    if lidar_mode is not None:
+        from gym_auv_amd import _lib
+
+        sim.set_option(_lib.OPT_LIDAR_MODE, lidar_mode)
     sim.set_scene(scene)
     return sim
 

@@ -16,9 +16,12 @@ from tests.helpers import assert_all_equal, make_oracle, make_sim, same_bits
 
 pytestmark = pytest.mark.gpu
 
+# both LiDAR kernels must give the oracle's bits: 0 = rasterising (default), 1 = all pairs
+MODES = pytest.mark.parametrize("mode", [0, 1], ids=["raster", "allpairs"])
 
-def _run_pair(cfg, scene, steps, seed, check_every=1):
-    sim = make_sim(cfg, scene)
+
+def _run_pair(cfg, scene, steps, seed, check_every=1, mode=None):
+    sim = make_sim(cfg, scene, lidar_mode=mode)
     env = make_oracle(cfg, scene)
     sim.reset(scene["init_state"])
     env.reset(scene["init_state"])
@@ -32,31 +35,36 @@ def _run_pair(cfg, scene, steps, seed, check_every=1):
     sim.close()
 
 
-def test_cfg1_single_vessel_episode():
+@MODES
+def test_cfg1_single_vessel_episode(mode):
     cfg, scene = scenarios.make_workload("cfg1_single_episode")
-    _run_pair(cfg, scene, steps=300, seed=0, check_every=10)
+    _run_pair(cfg, scene, steps=300, seed=0, check_every=10, mode=mode)
 
 
-def test_cfg2_static_circles():
+@MODES
+def test_cfg2_static_circles(mode):
     cfg, scene = scenarios.make_workload("cfg2_4096_static", n_envs=300)
-    _run_pair(cfg, scene, steps=25, seed=1, check_every=5)
+    _run_pair(cfg, scene, steps=25, seed=1, check_every=5, mode=mode)
 
 
-def test_cfg3_moving_polygons():
+@MODES
+def test_cfg3_moving_polygons(mode):
     cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=333)
-    _run_pair(cfg, scene, steps=25, seed=2, check_every=5)
+    _run_pair(cfg, scene, steps=25, seed=2, check_every=5, mode=mode)
 
 
-def test_cfg5_dense_720_rays():
+@MODES
+def test_cfg5_dense_720_rays(mode):
     cfg, scene = scenarios.make_workload("cfg5_dense_720", n_envs=6)
-    _run_pair(cfg, scene, steps=3, seed=4)
+    _run_pair(cfg, scene, steps=3, seed=4, mode=mode)
 
 
-def test_empty_scene_and_absent_slots():
+@MODES
+def test_empty_scene_and_absent_slots(mode):
     # no obstacle slots at all
     cfg = params.make_config(70, 0, 0)
     scene = scenarios.make_scene(70, 0, 0, seed=11)
-    _run_pair(cfg, scene, steps=3, seed=11)
+    _run_pair(cfg, scene, steps=3, seed=11, mode=mode)
     # slots present but switched off (radius <= 0, nv == 0), ragged vertex counts
     cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=65)
     scene["circles"][::2, 1::2, 2] = 0.0
@@ -64,7 +72,7 @@ def test_empty_scene_and_absent_slots():
     scene["poly_nv"][::3, ::2] = 0
     scene["poly_nv"][1::3, 1] = 3
     scene["poly_nv"][2::3, 2] = 4
-    _run_pair(cfg, scene, steps=5, seed=12)
+    _run_pair(cfg, scene, steps=5, seed=12, mode=mode)
 
 
 def test_collisions_goal_and_truncation_flags():
@@ -108,6 +116,58 @@ def test_masked_reset_matches_oracle():
         env.step(acts[k])
     assert_all_equal(sim, env, "after steps following a masked reset")
     sim.close()
+
+
+def _adversarial_scene(V, seed):
+    """Geometry that stresses the candidate intervals of the rasterising
+    kernel: vessels inside / touching / grazing obstacles, tiny and huge
+    circles, slivers, edges through the vessel, obstacles straddling the
+    sensor range and the scan's wrap-around (dead astern)."""
+    rng = np.random.default_rng(seed)
+    C, P, NV = 6, 6, 6
+    cfg = params.make_config(V, C, P, NV)
+    scene = scenarios.make_scene(V, C, P, NV, seed=seed, extent=170.0, n_sides=6, width=(0.5, 60.0))
+    circ = scene["circles"]
+    circ[:, 0, 2] = rng.choice([1e-6, 1e-3, 0.05, 400.0], V)           # pin-points and giants
+    circ[:, 1, :2] = rng.normal(0.0, 3.0, (V, 2))                      # on top of the vessel
+    circ[:, 1, 2] = rng.uniform(0.5, 8.0, V)
+    ang = rng.uniform(-np.pi, np.pi, V)
+    rad = rng.uniform(5.0, 30.0, V)
+    d = 150.0 + rad * rng.choice([-1.0, -0.999999, 0.0, 0.999999, 1.0, 1.000001], V)
+    circ[:, 2, 0], circ[:, 2, 1], circ[:, 2, 2] = d * np.cos(ang), d * np.sin(ang), rad   # range edge
+    scene["poly_pose"][:, 0, :2] = rng.normal(0.0, 2.0, (V, 2))        # polygon around / through the vessel
+    scene["poly_pose"][:, 1, :2] = rng.normal(0.0, 40.0, (V, 2))
+    scene["poly_verts"][:, 2] *= np.array([1.0, 1e-4])                 # sliver
+    scene["poly_pose"][::7, 3, 2:4] = [1.0, 0.0]                       # unrotated, so that ...
+    scene["poly_verts"][::7, 3, 0] = -scene["poly_pose"][::7, 3, :2]   # ... vertex 0 sits exactly on the vessel
+    scene["init_state"][2, ::5] = rng.choice([-np.pi, np.pi - 1e-12, 0.0, np.pi / 2], len(range(0, V, 5)))
+    return cfg, scene
+
+
+def test_raster_equals_all_pairs_on_adversarial_geometry():
+    from gym_auv_amd import _lib
+
+    V = 20000
+    for seed in (101, 102):
+        cfg, scene = _adversarial_scene(V, seed)
+        out = []
+        for mode in (_lib.LIDAR_RASTER, _lib.LIDAR_ALL_PAIRS):
+            sim = make_sim(cfg, scene, lidar_mode=mode)
+            sim.reset(scene["init_state"])
+            acts = scenarios.random_actions(V, 3, seed=seed)
+            res = [(sim.read("ranges"), sim.read("hit"))]
+            for k in range(3):
+                sim.step_host(acts[k])
+                res.append((sim.read("ranges"), sim.read("hit")))
+            out.append(res)
+            sim.close()
+        for (r0, h0), (r1, h1) in zip(*out):
+            assert same_bits(r0, r1) and same_bits(h0, h1)
+        assert (out[0][0][1] >= 0).mean() > 0.2          # the scenes do produce hits
+    # and the oracle agrees on a slice of the same scenes
+    sub = {k: (v[:, :150] if k == "init_state" else v[:150]) for k, v in scene.items()}
+    sub_cfg = dict(cfg, n_envs=150)
+    _run_pair(sub_cfg, sub, steps=2, seed=7, mode=_lib.LIDAR_RASTER)
 
 
 def test_full_size_batch_against_oracle_sample():
