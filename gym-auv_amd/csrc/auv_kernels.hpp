@@ -45,6 +45,7 @@ struct DynArgs {
     double* poly_pose;     // [V,P,6]
     double dt, thrust_max, moment_max;
     double mp[MP_COUNT];
+    int advance;  // 1: also advance the obstacles here (0 when k_sense does it)
 };
 
 struct Vec6 {
@@ -86,72 +87,82 @@ __device__ __forceinline__ Vec6 axpy6(const Vec6& y, double h, const Vec6& a) {
     return o;
 }
 
-#define AUV_COMB2(f, c0, k0, c1, k1) ((c0) * (k0).f + (c1) * (k1).f)
 #define AUV_EACH6(M) M(x) M(y) M(psi) M(u) M(v) M(r)
+
+// One Fehlberg 4(5) step of size h (5th-order solution propagated), heading
+// wrapped afterwards; actions are clipped to [0,1] x [-1,1] first.
+__device__ __forceinline__ Vec6 rkf45_step(const Vec6& s, double a0, double a1, double h, double thrust_max,
+                                           double moment_max, const double* mp) {
+    a0 = a0 < 0.0 ? 0.0 : a0;
+    a0 = a0 > 1.0 ? 1.0 : a0;
+    a1 = a1 < -1.0 ? -1.0 : a1;
+    a1 = a1 > 1.0 ? 1.0 : a1;
+    const double fx = a0 * thrust_max;
+    const double mz = a1 * moment_max;
+    const Vec6 k0 = vessel_rhs(s, fx, mz, mp);
+    Vec6 acc;
+#define M(f) acc.f = (1.0 / 4.0) * k0.f;
+    AUV_EACH6(M)
+#undef M
+    const Vec6 k1 = vessel_rhs(axpy6(s, h, acc), fx, mz, mp);
+#define M(f) acc.f = (3.0 / 32.0) * k0.f + (9.0 / 32.0) * k1.f;
+    AUV_EACH6(M)
+#undef M
+    const Vec6 k2 = vessel_rhs(axpy6(s, h, acc), fx, mz, mp);
+#define M(f) acc.f = ((1932.0 / 2197.0) * k0.f + (-7200.0 / 2197.0) * k1.f) + (7296.0 / 2197.0) * k2.f;
+    AUV_EACH6(M)
+#undef M
+    const Vec6 k3 = vessel_rhs(axpy6(s, h, acc), fx, mz, mp);
+#define M(f) \
+    acc.f = (((439.0 / 216.0) * k0.f + (-8.0) * k1.f) + (3680.0 / 513.0) * k2.f) + (-845.0 / 4104.0) * k3.f;
+    AUV_EACH6(M)
+#undef M
+    const Vec6 k4 = vessel_rhs(axpy6(s, h, acc), fx, mz, mp);
+#define M(f)                                                                                   \
+    acc.f = ((((-8.0 / 27.0) * k0.f + 2.0 * k1.f) + (-3544.0 / 2565.0) * k2.f) +               \
+             (1859.0 / 4104.0) * k3.f) +                                                       \
+            (-11.0 / 40.0) * k4.f;
+    AUV_EACH6(M)
+#undef M
+    const Vec6 k5 = vessel_rhs(axpy6(s, h, acc), fx, mz, mp);
+#define M(f)                                                                                   \
+    acc.f = ((((16.0 / 135.0) * k0.f + (6656.0 / 12825.0) * k2.f) + (28561.0 / 56430.0) * k3.f) + \
+             (-9.0 / 50.0) * k4.f) +                                                           \
+            (2.0 / 55.0) * k5.f;
+    AUV_EACH6(M)
+#undef M
+    Vec6 o = axpy6(s, h, acc);
+    o.psi = wrap_angle(o.psi);
+    return o;
+}
+
+__device__ __forceinline__ Vec6 load_state(const double* state, int V, int i) {
+    Vec6 s;
+    s.x = state[0 * (size_t)V + i];
+    s.y = state[1 * (size_t)V + i];
+    s.psi = state[2 * (size_t)V + i];
+    s.u = state[3 * (size_t)V + i];
+    s.v = state[4 * (size_t)V + i];
+    s.r = state[5 * (size_t)V + i];
+    return s;
+}
+
+__device__ __forceinline__ void store_state(double* state, int V, int i, const Vec6& o) {
+    state[0 * (size_t)V + i] = o.x;
+    state[1 * (size_t)V + i] = o.y;
+    state[2 * (size_t)V + i] = o.psi;
+    state[3 * (size_t)V + i] = o.u;
+    state[4 * (size_t)V + i] = o.v;
+    state[5 * (size_t)V + i] = o.r;
+}
 
 __global__ __launch_bounds__(256) void k_dynamics(DynArgs a) {
     const int V = a.d.V;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < V) {
-        Vec6 s;
-        s.x = a.state[0 * (size_t)V + i];
-        s.y = a.state[1 * (size_t)V + i];
-        s.psi = a.state[2 * (size_t)V + i];
-        s.u = a.state[3 * (size_t)V + i];
-        s.v = a.state[4 * (size_t)V + i];
-        s.r = a.state[5 * (size_t)V + i];
-        double a0 = a.action[i];
-        double a1 = a.action[(size_t)V + i];
-        a0 = a0 < 0.0 ? 0.0 : a0;
-        a0 = a0 > 1.0 ? 1.0 : a0;
-        a1 = a1 < -1.0 ? -1.0 : a1;
-        a1 = a1 > 1.0 ? 1.0 : a1;
-        const double fx = a0 * a.thrust_max;
-        const double mz = a1 * a.moment_max;
-        const double h = a.dt;
-        const double* mp = a.mp;
-
-        // Fehlberg 4(5) tableau; the 5th-order solution is propagated.
-        const Vec6 k0 = vessel_rhs(s, fx, mz, mp);
-        Vec6 acc;
-#define M(f) acc.f = (1.0 / 4.0) * k0.f;
-        AUV_EACH6(M)
-#undef M
-        const Vec6 k1 = vessel_rhs(axpy6(s, h, acc), fx, mz, mp);
-#define M(f) acc.f = (3.0 / 32.0) * k0.f + (9.0 / 32.0) * k1.f;
-        AUV_EACH6(M)
-#undef M
-        const Vec6 k2 = vessel_rhs(axpy6(s, h, acc), fx, mz, mp);
-#define M(f) acc.f = ((1932.0 / 2197.0) * k0.f + (-7200.0 / 2197.0) * k1.f) + (7296.0 / 2197.0) * k2.f;
-        AUV_EACH6(M)
-#undef M
-        const Vec6 k3 = vessel_rhs(axpy6(s, h, acc), fx, mz, mp);
-#define M(f) \
-    acc.f = (((439.0 / 216.0) * k0.f + (-8.0) * k1.f) + (3680.0 / 513.0) * k2.f) + (-845.0 / 4104.0) * k3.f;
-        AUV_EACH6(M)
-#undef M
-        const Vec6 k4 = vessel_rhs(axpy6(s, h, acc), fx, mz, mp);
-#define M(f)                                                                                   \
-    acc.f = ((((-8.0 / 27.0) * k0.f + 2.0 * k1.f) + (-3544.0 / 2565.0) * k2.f) +               \
-             (1859.0 / 4104.0) * k3.f) +                                                       \
-            (-11.0 / 40.0) * k4.f;
-        AUV_EACH6(M)
-#undef M
-        const Vec6 k5 = vessel_rhs(axpy6(s, h, acc), fx, mz, mp);
-#define M(f)                                                                                   \
-    acc.f = ((((16.0 / 135.0) * k0.f + (6656.0 / 12825.0) * k2.f) + (28561.0 / 56430.0) * k3.f) + \
-             (-9.0 / 50.0) * k4.f) +                                                           \
-            (2.0 / 55.0) * k5.f;
-        AUV_EACH6(M)
-#undef M
-        Vec6 o = axpy6(s, h, acc);
-        o.psi = wrap_angle(o.psi);
-        a.state[0 * (size_t)V + i] = o.x;
-        a.state[1 * (size_t)V + i] = o.y;
-        a.state[2 * (size_t)V + i] = o.psi;
-        a.state[3 * (size_t)V + i] = o.u;
-        a.state[4 * (size_t)V + i] = o.v;
-        a.state[5 * (size_t)V + i] = o.r;
+        const Vec6 s = load_state(a.state, V, i);
+        const Vec6 o = rkf45_step(s, a.action[i], a.action[(size_t)V + i], a.dt, a.thrust_max, a.moment_max, a.mp);
+        store_state(a.state, V, i, o);
         a.t_step[i] = a.t_step[i] + 1;
     }
     // constant-velocity obstacle advance: slot i of the flattened
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(256) void k_dynamics(DynArgs a) {
     const long long n_c = (long long)V * a.d.C;
     const long long n_p = (long long)V * a.d.P;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long j = i; j < n_c + n_p; j += stride) {
+    for (long long j = i; a.advance && j < n_c + n_p; j += stride) {
         if (j < n_c) {
             double* c = a.circles + j * 5;
             c[0] = c[0] + c[3] * a.dt;

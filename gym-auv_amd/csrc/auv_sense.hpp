@@ -1,0 +1,575 @@
+// The step as two launches: a vessel-centric kernel and a scene-centric kernel.
+//
+// k_vessel   one thread per vessel: RKF45 step (skipped after a reset), then
+//            everything that depends on the vessel and its path only: heading
+//            sin/cos, own velocity, navigation features, along-track progress,
+//            goal / truncation flags, the scene-independent part of the reward.
+// k_sense    one workgroup per tile of envs, reading their scene ONCE from HBM:
+//   1. (step only) advances the constant-velocity obstacles, writes them back;
+//   2. makes every primitive vessel-relative in LDS, with its candidate ray
+//      interval (auv_lidar_raster.hpp) and, per polygon edge, its distance to
+//      the vessel and its crossing-number bit; circle threads also finish
+//      their obstacle's metadata and risk, two edge threads per polygon
+//      compute its bearing and course;
+//   3. per polygon: signed hull distance from its edges, metadata, risk;
+//      per env: nearest obstacle, collision, reward, done;
+//   4. LiDAR: dense (primitive, ray) pair list, exact fp64 tests, LDS atomic
+//      min per ray, id resolution, then 16 B per ray written out.
+// Results are bit-identical to k_dynamics(advance) + k_encounter + k_lidar.
+#pragma once
+#include "auv_lidar_raster.hpp"
+
+namespace auv {
+
+// per-vessel record handed from k_vessel to k_sense, f64 [V,8]
+enum EnvRec { ER_COS = 0, ER_SIN, ER_VOX, ER_VOY, ER_REWARD, ER_COUNT = 8 };
+
+struct VesselArgs {
+    int V;
+    int do_step;  // 1: integrate and count the step; 0: state was just (re)set
+    int max_steps;
+    double* state;         // [6,V]
+    const double* action;  // [2,V]
+    int32_t* t_step;
+    const double* path;  // [V,6]
+    double* envrec;      // [V,8]
+    double* own;         // [V,2]
+    double* along;       // [V]
+    float* navigation;   // [V,1,6]
+    uint8_t* reached_goal;
+    uint8_t* truncated;
+    double dt, thrust_max, moment_max, look_ahead, goal_radius, rw_progress, rw_cte;
+    double mp[MP_COUNT];
+};
+
+__global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
+    const int V = a.V;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    Vec6 s = load_state(a.state, V, i);
+    int t = a.t_step[i];
+    if (a.do_step) {
+        s = rkf45_step(s, a.action[i], a.action[(size_t)V + i], a.dt, a.thrust_max, a.moment_max, a.mp);
+        store_state(a.state, V, i, s);
+        t = t + 1;
+        a.t_step[i] = t;
+    }
+    const SinCos sc = sincos_det(s.psi);
+    const double vox = sc.c * s.u - sc.s * s.v;
+    const double voy = sc.s * s.u + sc.c * s.v;
+    a.own[2 * (size_t)i] = __builtin_sqrt(vox * vox + voy * voy);
+    a.own[2 * (size_t)i + 1] = s.psi;
+    const double* pt = a.path + (size_t)i * 6;
+    const double x0 = pt[0], y0 = pt[1], ang = pt[2], ca = pt[3], sa = pt[4], len = pt[5];
+    const double rx = s.x - x0;
+    const double ry = s.y - y0;
+    const double al = rx * ca + ry * sa;
+    const double cte = ry * ca - rx * sa;
+    const double tx = x0 + (al + a.look_ahead) * ca;
+    const double ty = y0 + (al + a.look_ahead) * sa;
+    const double la = wrap_angle(atan2_det(ty - s.y, tx - s.x) - s.psi);
+    const double he = wrap_angle(ang - s.psi);
+    float* nav = a.navigation + (size_t)i * 6;
+    nav[0] = (float)s.u;
+    nav[1] = (float)s.v;
+    nav[2] = (float)s.r;
+    nav[3] = (float)la;
+    nav[4] = (float)he;
+    nav[5] = (float)cte;
+    const double al_prev = a.along[i];
+    a.along[i] = al;
+    a.reached_goal[i] = ((len - al) <= a.goal_radius) ? 1 : 0;
+    a.truncated[i] = (t >= a.max_steps) ? 1 : 0;
+    double rew = 0.0;
+    if (a.do_step) {
+        rew = a.rw_progress * (al - al_prev);
+        rew = rew - a.rw_cte * __builtin_fabs(cte);
+    }
+    double* er = a.envrec + (size_t)i * ER_COUNT;
+    er[ER_COS] = sc.c;
+    er[ER_SIN] = sc.s;
+    er[ER_VOX] = vox;
+    er[ER_VOY] = voy;
+    er[ER_REWARD] = rew;
+}
+
+struct SenseArgs {
+    Dims d;
+    int TE;       // envs per workgroup
+    int cap;      // pair-list slots per round
+    int is_step;  // 1: advance obstacles, finish the reward; 0: after reset / plain sense
+    const double* state;
+    const double* envrec;
+    double* circles;    // [V,C,5]  positions updated in place when is_step
+    double* poly_pose;  // [V,P,6]
+    const double* poly_verts;
+    const int32_t* poly_nv;
+    const double* poly_heading;
+    const double* ray_dirs;
+    double* ranges;
+    int32_t* hit;
+    float* perception;
+    double* obst_dist;
+    double* risk;
+    double* meta;
+    uint8_t* collision;
+    const uint8_t* reached_goal;
+    const uint8_t* truncated;
+    uint8_t* done;
+    double* min_dist;
+    int32_t* min_idx;
+    double* reward;
+    double dt, sensor_range, vessel_radius;
+    double w_d, w_c, t_c;
+    double rw_collision, rw_goal;
+};
+
+struct SenseLayout {
+    size_t env, circ, seg, best, obst, edist, meta, offs, ids, pairs, ecross, wsum, total;  // byte offsets
+};
+
+// LDS image per tile (f64 blocks first, 16-B aligned int4 block, then words).
+//   env[TE][2] cos psi, sin psi       circ[TE*C][3] mx,my,cc       seg[TE*S][5] ax,ay,ex,ey,nt
+//   best[TE*R] u64                    obst[TE*O][8] mx,my,rvx,rvy,bearing,course,dist,-
+//   edist[TE*S] f64   meta[NP] int4   offs[NP+1]   ids[TE*R]   pairs[cap]   ecross[TE*S]   wsum[8]
+__host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P, int NV, int cap) {
+    SenseLayout L;
+    const size_t S = (size_t)P * NV, O = (size_t)C + P;
+    const size_t NP = (size_t)TE * ((size_t)C + S);
+    size_t o = 0;
+    L.env = o; o += (size_t)TE * 2 * 8;
+    L.circ = o; o += (size_t)TE * C * 3 * 8;
+    L.seg = o; o += (size_t)TE * S * 5 * 8;
+    L.best = o; o += (size_t)TE * R * 8;
+    L.obst = o; o += (size_t)TE * O * 8 * 8;
+    L.edist = o; o += (size_t)TE * S * 8;
+    o = (o + 15) & ~(size_t)15;
+    L.meta = o; o += NP * 16;
+    L.offs = o; o += (NP + 1) * 4;
+    L.ids = o; o += (size_t)TE * R * 4;
+    L.pairs = o; o += (size_t)cap * 4;
+    L.ecross = o; o += (size_t)TE * S * 4;
+    L.wsum = o; o += 8 * 4;
+    L.total = (o + 15) & ~(size_t)15;
+    return L;
+}
+
+enum ObstRec { OB_MX = 0, OB_MY, OB_RVX, OB_RVY, OB_BEARING, OB_COURSE, OB_DIST, OB_COUNT = 8 };
+
+// One (primitive, ray) pair of the dense list: decode, build the ray, run the
+// exact test.  `slot` = accumulator index of the ray, `oid` = obstacle id.
+struct PairHit {
+    bool ok;
+    int slot;
+    unsigned int oid;
+    unsigned long long key;
+};
+
+__device__ __forceinline__ PairHit pair_test(unsigned int pr, int R, int n_circ, double range, const int4* meta,
+                                             const double* env, const double* circ, const double* seg,
+                                             const double* ray_dirs) {
+    const int p = (int)(pr >> 16);
+    const int4 m = meta[p];
+    int r = m.x + (int)(pr & 0xffffu);
+    r = r >= R ? r - R : r;
+    const double cpsi = env[m.z * 2], spsi = env[m.z * 2 + 1];
+    const double cb = ray_dirs[2 * r], sb = ray_dirs[2 * r + 1];
+    const double dx = cpsi * cb - spsi * sb;
+    const double dy = spsi * cb + cpsi * sb;
+    double t = 0.0;
+    bool ok;
+    if (p < n_circ) {
+        ok = circle_hit(circ[3 * p], circ[3 * p + 1], circ[3 * p + 2], dx, dy, t);
+    } else {
+        const double* sg = seg + (size_t)(p - n_circ) * 5;
+        ok = edge_hit(sg[0], sg[1], sg[2], sg[3], sg[4], dx, dy, t);
+    }
+    PairHit h;
+    h.ok = ok && t < range;
+    h.slot = m.z * R + r;
+    h.oid = (unsigned int)m.w;
+    h.key = t_key(t);
+    return h;
+}
+
+// default risk index of one obstacle (m = centre relative to the vessel, rv =
+// relative velocity, dist = signed hull distance)
+__device__ __forceinline__ double risk_index(double mx, double my, double rvx, double rvy, double vv, double dist,
+                                             double range, double w_d, double w_c, double t_c) {
+    const double d = dist < 0.0 ? 0.0 : dist;
+    const bool inrange = d < range;
+    const double fd = 1.0 - (inrange ? d : 0.0) / range;
+    const double term_d = w_d * (fd * fd);
+    const double closing = 0.0 - (mx * rvx + my * rvy);
+    const bool has_c = (vv > 0.0) && (closing > 0.0);
+    const double tcpa = (has_c ? closing : 0.0) / (has_c ? vv : 1.0);
+    const double qx = mx + rvx * tcpa;
+    const double qy = my + rvy * tcpa;
+    const double dcpa = __builtin_sqrt(qx * qx + qy * qy);
+    const double fc = 1.0 - (dcpa < range ? dcpa : range) / range;
+    const double term_c = (w_c * (fc * fc)) * (t_c / (t_c + tcpa));
+    const double rr = term_d + (has_c ? term_c : 0.0);
+    return inrange ? rr : 0.0;
+}
+
+constexpr int kKeep = 4;  // pair-list passes whose hit keys stay in registers between the two sweeps
+
+__global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int V = a.d.V, R = a.d.R, C = a.d.C, P = a.d.P, NV = a.d.NV, O = a.d.O;
+    const int S = P * NV;
+    const int TE = a.TE;
+    const SenseLayout L = sense_layout(TE, R, C, P, NV, a.cap);
+    double* env = reinterpret_cast<double*>(lds_raw + L.env);
+    double* circ = reinterpret_cast<double*>(lds_raw + L.circ);
+    double* seg = reinterpret_cast<double*>(lds_raw + L.seg);
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(lds_raw + L.best);
+    double* obst = reinterpret_cast<double*>(lds_raw + L.obst);
+    double* edist = reinterpret_cast<double*>(lds_raw + L.edist);
+    int4* meta = reinterpret_cast<int4*>(lds_raw + L.meta);
+    int* offs = reinterpret_cast<int*>(lds_raw + L.offs);
+    unsigned int* ids = reinterpret_cast<unsigned int*>(lds_raw + L.ids);
+    unsigned int* pairs = reinterpret_cast<unsigned int*>(lds_raw + L.pairs);
+    int* ecross = reinterpret_cast<int*>(lds_raw + L.ecross);
+    int* wsum = reinterpret_cast<int*>(lds_raw + L.wsum);
+    const int e0 = blockIdx.x * TE;
+    const int ne = min(TE, V - e0);
+    const int n_circ = ne * C;
+    const int NP = n_circ + ne * S;
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const double range = a.sensor_range;
+    const float frange = (float)range * kRangeSlack;
+    const float inv_delta = (float)R * (1.0f / 6.2831853f);
+    const float half_scan = 0.5f * (float)R;
+
+    // ---- phase 1: per-ray accumulators, heading sin/cos, primitives.  Nothing
+    // here reads LDS written by another thread, so no barrier is needed before.
+    for (int el = tid; el < ne; el += nthr) {
+        const double* er = a.envrec + (size_t)(e0 + el) * ER_COUNT;
+        env[el * 2] = er[ER_COS];
+        env[el * 2 + 1] = er[ER_SIN];
+    }
+    const unsigned long long range_bits = (unsigned long long)__double_as_longlong(range);
+    for (int f = tid; f < ne * R; f += nthr) {
+        best[f] = range_bits;
+        ids[f] = 0xffffffffu;
+    }
+    // circles go to the highest thread ids, so that on small tiles they do not
+    // share a wave with the first edges
+    for (int i = nthr - 1 - tid; i < n_circ; i += nthr) {
+        const int el = i / C;
+        const int j = i - el * C;
+        const int e = e0 + el;
+        double* c = a.circles + ((size_t)e0 * C + i) * 5;
+        double cx = c[0], cy = c[1];
+        const double rad = c[2], vx = c[3], vy = c[4];
+        if (a.is_step) {
+            cx = cx + vx * a.dt;
+            cy = cy + vy * a.dt;
+            c[0] = cx;
+            c[1] = cy;
+        }
+        const double psi = a.state[2 * (size_t)V + e];
+        const double* er = a.envrec + (size_t)e * ER_COUNT;
+        const double mx = cx - a.state[e];
+        const double my = cy - a.state[(size_t)V + e];
+        const double mm = mx * mx + my * my;
+        const double cc = mm - rad * rad;
+        const bool on = rad > 0.0;
+        circ[i * 3 + 0] = on ? mx : 0.0;
+        circ[i * 3 + 1] = on ? my : 0.0;
+        circ[i * 3 + 2] = on ? cc : __builtin_inf();
+        // obstacle record for phase 2
+        double* ob = obst + ((size_t)el * O + j) * OB_COUNT;
+        ob[OB_MX] = mx;
+        ob[OB_MY] = my;
+        ob[OB_RVX] = vx - er[ER_VOX];
+        ob[OB_RVY] = vy - er[ER_VOY];
+        ob[OB_DIST] = on ? (__builtin_sqrt(mm) - rad) - a.vessel_radius : __builtin_inf();
+        // candidate rays
+        const float fr = (float)rad, fmx = (float)mx, fmy = (float)my;
+        const float fmm = fmx * fmx + fmy * fmy;
+        int2 iv = make_int2(0, 0);
+        if (!on) {
+            // absent slot
+        } else if (!(fmm > fr * fr * 1.001f)) {
+            iv.y = R;  // vessel inside or touching: every ray can hit
+        } else if (sqrtf(fmm) - fr > frange) {
+            // wholly beyond sensor range
+        } else {
+            const float xc = scan_index(atan2f(fmy, fmx), (float)psi, inv_delta);
+            const float hw = atan2f(fr, sqrtf(fmm - fr * fr)) * inv_delta;
+            iv = make_interval(xc - hw, xc + hw, R);
+        }
+        meta[i] = make_int4(iv.x, iv.y, el, j);
+    }
+    for (int i = tid; i < ne * S; i += nthr) {
+        const int el = i / S;
+        const int s = i - el * S;
+        const int q = s / NV;
+        const int k = s - q * NV;
+        const int e = e0 + el;
+        const size_t ep = (size_t)e * P + q;
+        const int nv = a.poly_nv[ep];
+        const double* p = a.poly_pose + ep * 6;
+        double X = p[0], Y = p[1];
+        const double ch = p[2], sh = p[3], pvx = p[4], pvy = p[5];
+        if (a.is_step) {
+            X = X + pvx * a.dt;
+            Y = Y + pvy * a.dt;
+        }
+        const double px = a.state[e], py = a.state[(size_t)V + e];
+        const double psi = a.state[2 * (size_t)V + e];
+        if (k == 0) {
+            // one edge thread per polygon files its obstacle record for phase 2
+            const double* er = a.envrec + (size_t)e * ER_COUNT;
+            double* ob = obst + ((size_t)el * O + C + q) * OB_COUNT;
+            ob[OB_MX] = X - px;
+            ob[OB_MY] = Y - py;
+            ob[OB_RVX] = pvx - er[ER_VOX];
+            ob[OB_RVY] = pvy - er[ER_VOY];
+        }
+        double ax = 0.0, ay = 0.0, ex = 0.0, ey = 0.0, nt = 0.0, dd = __builtin_inf();
+        int cross = 0;
+        int2 iv = make_int2(0, 0);
+        if (k < nv) {
+            const double* vb = a.poly_verts + ep * NV * 2;
+            const int k1 = (k + 1 < nv) ? k + 1 : 0;
+            const double Ax = X + (ch * vb[2 * k] - sh * vb[2 * k + 1]);
+            const double Ay = Y + (sh * vb[2 * k] + ch * vb[2 * k + 1]);
+            const double Bx = X + (ch * vb[2 * k1] - sh * vb[2 * k1 + 1]);
+            const double By = Y + (sh * vb[2 * k1] + ch * vb[2 * k1 + 1]);
+            ax = Ax - px;
+            ay = Ay - py;
+            const double by = By - py;
+            ex = Bx - Ax;
+            ey = By - Ay;
+            nt = ax * ey - ay * ex;
+            // point-to-edge distance and crossing-number bit (vessel at the origin)
+            const double ee = ex * ex + ey * ey;
+            double tp = 0.0;
+            if (ee > 0.0) {
+                tp = (0.0 - (ax * ex + ay * ey)) / ee;
+                tp = tp < 0.0 ? 0.0 : tp;
+                tp = tp > 1.0 ? 1.0 : tp;
+            }
+            const double qx = ax + tp * ex;
+            const double qy = ay + tp * ey;
+            dd = __builtin_sqrt(qx * qx + qy * qy);
+            const bool up = (ay <= 0.0) && (by > 0.0) && (nt > 0.0);
+            const bool dn = (by <= 0.0) && (ay > 0.0) && (nt < 0.0);
+            cross = (up || dn) ? 1 : 0;
+            // candidate rays: the arc between the bearings of the two endpoints
+            const float fax = (float)ax, fay = (float)ay, fex = (float)ex, fey = (float)ey;
+            const float fbx = fax + fex, fby = fay + fey;
+            const float dmin = (float)dd;
+            const float aa = fax * fax + fay * fay, bb = fbx * fbx + fby * fby;
+            if (dmin > frange) {
+                // wholly beyond sensor range: stays empty
+            } else if (aa < 1e-6f || bb < 1e-6f || dmin < 1e-3f) {
+                iv.y = R;  // an endpoint (or the edge) is on top of the vessel: bearings are meaningless
+            } else {
+                const float xa = scan_index(atan2f(fay, fax), (float)psi, inv_delta);
+                const float xb = scan_index(atan2f(fby, fbx), (float)psi, inv_delta);
+                float d = xb - xa;
+                d = d > half_scan ? d - (float)R : d;
+                d = d < -half_scan ? d + (float)R : d;
+                if (fabsf(d) > half_scan - 1.5f) {
+                    iv.y = R;  // subtends ~180 deg: the short way round is ambiguous
+                } else {
+                    const float lo = d >= 0.0f ? xa : xa + d;
+                    iv = make_interval(lo, lo + fabsf(d), R);
+                }
+            }
+        }
+        double* sg = seg + (size_t)i * 5;
+        sg[0] = ax;
+        sg[1] = ay;
+        sg[2] = ex;
+        sg[3] = ey;
+        sg[4] = nt;
+        edist[i] = dd;
+        ecross[i] = cross;
+        meta[n_circ + i] = make_int4(iv.x, iv.y, el, C + q);
+    }
+    __syncthreads();
+
+    // ---- phase 2a: prefix sum of the interval lengths (thread-local + wave scan)
+    const int chunk = (NP + nthr - 1) / nthr;
+    const int p_lo = min(tid * chunk, NP), p_hi = min(p_lo + chunk, NP);
+    int mine = 0;
+    for (int p = p_lo; p < p_hi; ++p) mine += meta[p].y;
+    int incl = mine;
+    const int lane = tid & 63;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) wsum[tid >> 6] = incl;
+
+    // ---- phase 2b: obstacle-level outputs.  Three independent tasks per
+    // obstacle, each on a wave of its own so that no wave runs two of the long
+    // fp64 chains back to back: 0 = distance (polygons: from their edges; also
+    // the deferred write-back of the advanced position), relative speed and
+    // risk; 1 = bearing; 2 = course.
+    {
+        const int n_waves = nthr >> 6;
+        const int wave = tid >> 6;
+        for (int task = wave; task < 3; task += n_waves) {
+            for (int i = lane; i < ne * O; i += 64) {
+                const int el = i / O;
+                const int o = i - el * O;
+                const int e = e0 + el;
+                double* ob = obst + (size_t)i * OB_COUNT;
+                const double mx = ob[OB_MX], my = ob[OB_MY], rvx = ob[OB_RVX], rvy = ob[OB_RVY];
+                const size_t eo = (size_t)e * O + o;
+                double* m = a.meta + eo * 5;
+                if (task == 0) {
+                    double dist = ob[OB_DIST];
+                    double hd = 0.0;
+                    if (o >= C) {
+                        const int q = o - C;
+                        const size_t ep = (size_t)e * P + q;
+                        if (a.is_step) {
+                            // every edge thread has read the old position before the barrier
+                            double* p = a.poly_pose + ep * 6;
+                            p[0] = p[0] + p[4] * a.dt;
+                            p[1] = p[1] + p[5] * a.dt;
+                        }
+                        const int nv = a.poly_nv[ep];
+                        double dmin = __builtin_inf();
+                        int par = 0;
+                        const int s0 = el * S + q * NV;
+                        for (int k = 0; k < nv; ++k) {
+                            const double dd = edist[s0 + k];
+                            dmin = dd < dmin ? dd : dmin;
+                            par ^= ecross[s0 + k];
+                        }
+                        dist = nv > 0 ? (par ? -dmin : dmin) - a.vessel_radius : __builtin_inf();
+                        ob[OB_DIST] = dist;
+                        hd = a.poly_heading[ep];
+                    }
+                    const double vv = rvx * rvx + rvy * rvy;
+                    a.obst_dist[eo] = dist;
+                    m[0] = hd;
+                    m[1] = dist;
+                    m[2] = __builtin_sqrt(vv);
+                    a.risk[eo] = risk_index(mx, my, rvx, rvy, vv, dist, range, a.w_d, a.w_c, a.t_c);
+                } else {
+                    const double psi = a.state[2 * (size_t)V + e];
+                    m[2 + task] = wrap_angle(atan2_det(task == 1 ? my : rvy, task == 1 ? mx : rvx) - psi);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3a: finish the prefix sum
+    int base = 0;
+    for (int wv = 0; wv < (tid >> 6); ++wv) base += wsum[wv];
+    int run = base + incl - mine;
+    for (int p = p_lo; p < p_hi; ++p) {
+        offs[p] = run;
+        run += meta[p].y;
+    }
+    int total = 0;
+    for (int wv = 0; wv < (nthr >> 6); ++wv) total += wsum[wv];
+
+    // ---- phase 3b: per env (highest thread ids): nearest obstacle, collision, reward, done
+    for (int el = nthr - 1 - tid; el < ne; el += nthr) {
+        const int e = e0 + el;
+        double bd = __builtin_inf();
+        int bi = -1;
+        for (int o = 0; o < O; ++o) {
+            const double d = obst[((size_t)el * O + o) * OB_COUNT + OB_DIST];
+            if (d < bd) {
+                bd = d;
+                bi = o;
+            }
+        }
+        const uint8_t coll = bd < 0.0 ? 1 : 0;
+        const uint8_t goal = a.reached_goal[e];
+        a.min_dist[e] = bd;
+        a.min_idx[e] = bi;
+        a.collision[e] = coll;
+        double rew = 0.0;
+        if (a.is_step) {
+            rew = a.envrec[(size_t)e * ER_COUNT + ER_REWARD];
+            rew = rew - (coll ? a.rw_collision : 0.0);
+            rew = rew + (goal ? a.rw_goal : 0.0);
+        }
+        a.reward[e] = rew;
+        a.done[e] = coll | goal | a.truncated[e];
+    }
+
+    // ---- phase 4: LiDAR sweeps over the dense pair list, `cap` pairs per round
+    // (offs[] of one thread's own primitives is all the expansion below reads
+    // when there is one round, but other rounds read all of it: barrier first)
+    __syncthreads();
+    const int n_rounds = (total + a.cap - 1) / a.cap;
+    if (n_rounds == 1) {
+        // common case: the keys of sweep 0 stay in registers, sweep 1 does no arithmetic
+        for (int p = tid; p < NP; p += nthr) {
+            const int o = offs[p];
+            const int cnt = meta[p].y;
+            for (int k = 0; k < cnt; ++k) pairs[o + k] = ((unsigned int)p << 16) | (unsigned int)k;
+        }
+        __syncthreads();
+        PairHit kept[kKeep];
+#pragma unroll
+        for (int j = 0; j < kKeep; ++j) {
+            kept[j].ok = false;
+            const int w = tid + j * nthr;
+            if (w < total) {
+                kept[j] = pair_test(pairs[w], R, n_circ, range, meta, env, circ, seg, a.ray_dirs);
+                if (kept[j].ok) atomicMin(&best[kept[j].slot], kept[j].key);
+            }
+        }
+        for (int w = tid + kKeep * nthr; w < total; w += nthr) {
+            const PairHit h = pair_test(pairs[w], R, n_circ, range, meta, env, circ, seg, a.ray_dirs);
+            if (h.ok) atomicMin(&best[h.slot], h.key);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kKeep; ++j)
+            if (kept[j].ok && best[kept[j].slot] == kept[j].key) atomicMin(&ids[kept[j].slot], kept[j].oid);
+        for (int w = tid + kKeep * nthr; w < total; w += nthr) {
+            const PairHit h = pair_test(pairs[w], R, n_circ, range, meta, env, circ, seg, a.ray_dirs);
+            if (h.ok && best[h.slot] == h.key) atomicMin(&ids[h.slot], h.oid);
+        }
+        __syncthreads();
+    } else {
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int rd = 0; rd < n_rounds; ++rd) {
+                const int w0 = rd * a.cap;
+                const int n_pairs = min(a.cap, total - w0);
+                for (int p = tid; p < NP; p += nthr) {
+                    const int o = offs[p];
+                    const int lo = max(o, w0), hi = min(o + meta[p].y, w0 + a.cap);
+                    for (int w = lo; w < hi; ++w) pairs[w - w0] = ((unsigned int)p << 16) | (unsigned int)(w - o);
+                }
+                __syncthreads();
+                for (int w = tid; w < n_pairs; w += nthr) {
+                    const PairHit h = pair_test(pairs[w], R, n_circ, range, meta, env, circ, seg, a.ray_dirs);
+                    if (h.ok) {
+                        if (pass == 0) atomicMin(&best[h.slot], h.key);
+                        else if (best[h.slot] == h.key) atomicMin(&ids[h.slot], h.oid);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- phase 5: 16 B per ray, coalesced
+    for (int f = tid; f < ne * R; f += nthr) {
+        const double t = __longlong_as_double((long long)best[f]);
+        const size_t out = (size_t)e0 * R + f;
+        a.ranges[out] = t;
+        a.hit[out] = (int)ids[f];
+        a.perception[out] = (float)(1.0 - t / range);
+    }
+}
+
+}  // namespace auv

@@ -15,6 +15,7 @@
 
 #include "auv_kernels.hpp"
 #include "auv_lidar_raster.hpp"
+#include "auv_sense.hpp"
 
 using namespace auv;
 
@@ -60,6 +61,7 @@ struct auv_sim {
     double* init_stage = nullptr;  // [6,V] staging for reset
     double* circles0 = nullptr;    // obstacle poses as uploaded (restored on reset)
     double* poly_pose0 = nullptr;
+    double* envrec = nullptr;      // [V,8] k_vessel -> k_sense hand-off
     uint8_t* mask_stage = nullptr;
     bool have_rays = false, have_scene = false, have_state = false;
     // launch geometry
@@ -129,25 +131,34 @@ T* bp(auv_sim* h, int which) {
 // NULL is HIP's default (null) stream, exactly as in the HIP API itself
 hipStream_t pick(auv_sim*, void* stream) { return (hipStream_t)stream; }
 
-// Tile of the rasterising LiDAR: `want` envs per workgroup, or (want <= 0) as
-// many as keep the LDS image under ~40 KiB (>= 3-4 workgroups per CU) while
-// the grid still has >= 1024 workgroups.  The pair list holds 2048 slots, or
-// fewer when one env's primitives leave less room under the 64 KiB window.
+// Pair-list slots for a tile of `te` envs: room for ~4 candidate rays per
+// primitive without a second round, between 1024 and 4096, a power of two.
+int pair_cap(const Dims& d, int te) {
+    const long long want = (long long)te * (d.C + d.P * d.NV) * 4;
+    int cap = 1024;
+    while (cap < 4096 && cap < want) cap <<= 1;
+    return cap;
+}
+
+// Tile of k_sense: `want` envs per workgroup, or (want <= 0) as many as keep
+// the LDS image under ~40 KiB (4 workgroups per CU) while the grid still has
+// >= 1024 workgroups.
 void set_raster_tile(auv_sim* h, int want) {
     const Dims& d = h->d;
     const int S = d.P * d.NV;
-    int cap = 2048;
-    while (cap > 256 && raster_layout(1, d.R, d.C, S, cap).total > kLdsMax) cap >>= 1;
+    auto bytes = [&](int te) { return sense_layout(te, d.R, d.C, d.P, d.NV, pair_cap(d, te)).total; };
     int te = want;
     if (te <= 0) {
         te = 16;
-        while (te > 1 && raster_layout(te, d.R, d.C, S, cap).total > 40u * 1024u) te >>= 1;
+        while (te > 1 && bytes(te) > 40u * 1024u) te >>= 1;
         while (te > 1 && (d.V + te - 1) / te < 1024) te >>= 1;
     }
-    while (te > 1 && raster_layout(te, d.R, d.C, S, cap).total > kLdsMax) te >>= 1;
+    while (te > 1 && bytes(te) > kLdsMax) te >>= 1;
+    int cap = pair_cap(d, te);
+    while (cap > 256 && sense_layout(te, d.R, d.C, d.P, d.NV, cap).total > kLdsMax) cap >>= 1;
     h->raster_te = te;
     h->raster_cap = cap;
-    h->raster_lds = raster_layout(te, d.R, d.C, S, cap).total;
+    h->raster_lds = sense_layout(te, d.R, d.C, d.P, d.NV, cap).total;
     // the pair list packs (primitive, ray offset) into 16 bits each
     if ((long long)te * (d.C + S) > 65535 || d.R > 65535) h->raster_lds = (size_t)1 << 30;
 }
@@ -179,7 +190,84 @@ void choose_geometry(auv_sim* h) {
     h->enc_lds = (size_t)eb * O * sizeof(double);
 }
 
+// Fused path: k_vessel (integration when do_step, then the vessel-only
+// outputs) followed by k_sense (scene pass).  `action` is only read when
+// do_step is set.
+int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const double* action) {
+    const Dims& d = h->d;
+    VesselArgs va;
+    va.V = d.V;
+    va.do_step = do_step;
+    va.max_steps = h->cfg.max_steps;
+    va.state = bp<double>(h, AUV_BUF_STATE);
+    va.action = action;
+    va.t_step = bp<int32_t>(h, AUV_BUF_T_STEP);
+    va.path = h->path;
+    va.envrec = h->envrec;
+    va.own = bp<double>(h, AUV_BUF_OWN);
+    va.along = bp<double>(h, AUV_BUF_ALONG);
+    va.navigation = bp<float>(h, AUV_BUF_NAVIGATION);
+    va.reached_goal = bp<uint8_t>(h, AUV_BUF_REACHED_GOAL);
+    va.truncated = bp<uint8_t>(h, AUV_BUF_TRUNCATED);
+    va.dt = h->cfg.dt;
+    va.thrust_max = h->cfg.thrust_max;
+    va.moment_max = h->cfg.moment_max;
+    va.look_ahead = h->cfg.look_ahead;
+    va.goal_radius = h->cfg.goal_radius;
+    va.rw_progress = h->cfg.reward[0];
+    va.rw_cte = h->cfg.reward[3];
+    for (int i = 0; i < MP_COUNT; ++i) va.mp[i] = h->cfg.model[i];
+    hipLaunchKernelGGL(k_vessel, dim3((d.V + 255) / 256), dim3(256), 0, st, va);
+    HIP_TRY(h, hipGetLastError());
+    if (ev) {
+        HIP_TRY(h, hipEventRecord(ev[1], st));
+        HIP_TRY(h, hipEventRecord(ev[2], st));  // no separate encounter kernel on this path
+    }
+    SenseArgs sa;
+    sa.d = d;
+    sa.TE = h->raster_te;
+    sa.cap = h->raster_cap;
+    sa.is_step = do_step;
+    sa.state = bp<double>(h, AUV_BUF_STATE);
+    sa.envrec = h->envrec;
+    sa.circles = bp<double>(h, AUV_BUF_CIRCLES);
+    sa.poly_pose = bp<double>(h, AUV_BUF_POLY_POSE);
+    sa.poly_verts = h->poly_verts;
+    sa.poly_nv = h->poly_nv;
+    sa.poly_heading = h->poly_heading;
+    sa.ray_dirs = h->ray_dirs;
+    sa.ranges = bp<double>(h, AUV_BUF_RANGES);
+    sa.hit = bp<int32_t>(h, AUV_BUF_HIT);
+    sa.perception = bp<float>(h, AUV_BUF_PERCEPTION);
+    sa.obst_dist = bp<double>(h, AUV_BUF_OBST_DIST);
+    sa.risk = bp<double>(h, AUV_BUF_RISK);
+    sa.meta = bp<double>(h, AUV_BUF_META);
+    sa.collision = bp<uint8_t>(h, AUV_BUF_COLLISION);
+    sa.reached_goal = bp<uint8_t>(h, AUV_BUF_REACHED_GOAL);
+    sa.truncated = bp<uint8_t>(h, AUV_BUF_TRUNCATED);
+    sa.done = bp<uint8_t>(h, AUV_BUF_DONE);
+    sa.min_dist = bp<double>(h, AUV_BUF_MIN_DIST);
+    sa.min_idx = bp<int32_t>(h, AUV_BUF_MIN_IDX);
+    sa.reward = bp<double>(h, AUV_BUF_REWARD);
+    sa.dt = h->cfg.dt;
+    sa.sensor_range = h->cfg.sensor_range;
+    sa.vessel_radius = h->cfg.vessel_radius;
+    sa.w_d = h->cfg.risk[0];
+    sa.w_c = h->cfg.risk[1];
+    sa.t_c = h->cfg.risk[2];
+    sa.rw_collision = h->cfg.reward[1];
+    sa.rw_goal = h->cfg.reward[2];
+    const int blocks = (d.V + h->raster_te - 1) / h->raster_te;
+    hipLaunchKernelGGL(k_sense, dim3(blocks), dim3(256), h->raster_lds, st, sa);
+    HIP_TRY(h, hipGetLastError());
+    if (ev) HIP_TRY(h, hipEventRecord(ev[3], st));
+    return AUV_OK;
+}
+
+// Sensing on the all-pairs (cross-check) path, or, for a call that is not part
+// of a step, on either path.
 int launch_sense(auv_sim* h, hipStream_t st, hipEvent_t* ev, int is_step) {
+    if (h->lidar_mode == AUV_LIDAR_RASTER) return launch_fused(h, st, ev, 0, nullptr);
     const Dims& d = h->d;
     EncArgs ea;
     ea.d = d;
@@ -236,17 +324,8 @@ int launch_sense(auv_sim* h, hipStream_t st, hipEvent_t* ev, int is_step) {
     la.hit = bp<int32_t>(h, AUV_BUF_HIT);
     la.perception = bp<float>(h, AUV_BUF_PERCEPTION);
     la.sensor_range = h->cfg.sensor_range;
-    if (h->lidar_mode == AUV_LIDAR_ALL_PAIRS) {
-        const int lid_blocks = (d.V + h->lidar_te - 1) / h->lidar_te;
-        hipLaunchKernelGGL(k_lidar, dim3(lid_blocks), dim3(h->lidar_block), h->lidar_lds, st, la);
-    } else {
-        RasterArgs ra;
-        ra.l = la;
-        ra.l.TE = h->raster_te;
-        ra.cap = h->raster_cap;
-        const int lid_blocks = (d.V + h->raster_te - 1) / h->raster_te;
-        hipLaunchKernelGGL(k_lidar_raster, dim3(lid_blocks), dim3(256), h->raster_lds, st, ra);
-    }
+    const int lid_blocks = (d.V + h->lidar_te - 1) / h->lidar_te;
+    hipLaunchKernelGGL(k_lidar, dim3(lid_blocks), dim3(h->lidar_block), h->lidar_lds, st, la);
     HIP_TRY(h, hipGetLastError());
     if (ev) HIP_TRY(h, hipEventRecord(ev[3], st));
     return AUV_OK;
@@ -287,6 +366,12 @@ int do_step(auv_sim* h, const double* action_dev, hipStream_t st) {
         ev = &h->events[(size_t)h->prof_pending * 4];
         HIP_TRY(h, hipEventRecord(ev[0], st));
     }
+    if (h->lidar_mode == AUV_LIDAR_RASTER) {
+        int rc = launch_fused(h, st, ev, 1, action_dev ? action_dev : bp<double>(h, AUV_BUF_ACTION));
+        if (rc) return rc;
+        if (ev) h->prof_pending++;
+        return AUV_OK;
+    }
     DynArgs da;
     da.d = d;
     da.state = bp<double>(h, AUV_BUF_STATE);
@@ -298,6 +383,7 @@ int do_step(auv_sim* h, const double* action_dev, hipStream_t st) {
     da.thrust_max = h->cfg.thrust_max;
     da.moment_max = h->cfg.moment_max;
     for (int i = 0; i < MP_COUNT; ++i) da.mp[i] = h->cfg.model[i];
+    da.advance = 1;
     const long long work = (long long)d.V * (d.O > 1 ? d.O : 1);
     long long blocks = (work + 255) / 256;
     const long long min_blocks = ((long long)d.V + 255) / 256;
@@ -357,7 +443,7 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     d.O = d.C + d.P;
     choose_geometry(h);
     // dynamic LDS beyond the 64 KiB default window has to be granted per kernel
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lidar_raster), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sense), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsMax) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_lidar), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsMax) != hipSuccess) {
@@ -404,6 +490,7 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     chk(alloc_raw(h, &h->init_stage, (size_t)V * 6));
     chk(alloc_raw(h, &h->circles0, (size_t)V * C * 5));
     chk(alloc_raw(h, &h->poly_pose0, (size_t)V * P * 6));
+    chk(alloc_raw(h, &h->envrec, (size_t)V * ER_COUNT));
     chk(alloc_raw(h, &h->mask_stage, (size_t)V));
     if (rc == AUV_OK && hipDeviceSynchronize() != hipSuccess) rc = AUV_ERR_DEVICE;
     if (rc != AUV_OK) {
@@ -433,7 +520,7 @@ void auv_destroy(auv_handle h) {
     for (auto& b : h->buf)
         if (b.ptr) (void)hipFree(b.ptr);
     void* raw[] = {h->poly_verts, h->poly_nv, h->poly_heading, h->path, h->ray_dirs, h->init_stage, h->mask_stage,
-                   h->circles0, h->poly_pose0};
+                   h->circles0, h->poly_pose0, h->envrec};
     for (void* p : raw)
         if (p) (void)hipFree(p);
     delete h;
