@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--envs", type=int, default=None, help="override vessels per GPU")
     ap.add_argument("--lidar-mode", type=int, default=0, help="0 rasterising (default), 1 all pairs")
     ap.add_argument("--tile", type=int, default=0, help="envs per k_sense workgroup, 0 = auto")
+    ap.add_argument("--cnn", default="shallow", choices=["none", "shallow", "deep2", "deep"],
+                    help="LiDAR CNN fed zero-copy with every step's scans (features head)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=60)
@@ -113,6 +115,20 @@ def main():
     ptrs = [acts[i].data_ptr() for i in range(n_act)]
     done_t, coll_t, rew_t = sim.tensor("done"), sim.tensor("collision"), sim.tensor("reward")
 
+    # the consumer of the scans: the reference's shipped weights (fixture made from its own files)
+    net = feats = per_t = None
+    if args.cnn != "none" and R == 180:
+        import numpy as np
+
+        from gym_auv_amd import cnn
+
+        gold = np.load(os.path.join(ROOT, "tests", "golden", "cnn_golden.npz"))
+        pre = f"w_{args.cnn}/"
+        net = cnn.LidarCNN(args.cnn, {k[len(pre):]: gold[k] for k in gold.files if k.startswith(pre)},
+                           device=local_rank)
+        per_t = sim.tensor("perception")
+        feats = torch.empty((V, net.out_dim("features")), dtype=torch.float32, device=dev)
+
     def sync_all():
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -130,6 +146,8 @@ def main():
     def rollout():
         for k in range(args.steps):
             sim.step_device(ptrs[k % n_act], stream=stream)
+            if net is not None:
+                net.forward(per_t, "features", out=feats)
         return episode_stats()
 
     # bring a cold GPU to its working clocks first (a fresh process on an idle
@@ -138,6 +156,8 @@ def main():
     while time.perf_counter() - t_spin < 1.0:
         for k in range(50):
             sim.step_device(ptrs[k % n_act], stream=stream)
+            if net is not None:
+                net.forward(per_t, "features", out=feats)
         torch.cuda.synchronize(dev)
     for k in range(args.warmup):
         sim.step_device(ptrs[k % n_act], stream=stream)
@@ -157,6 +177,15 @@ def main():
     ev_elapsed = time.perf_counter() - t0
     prof_ms, prof_steps = sim.profile_read()
     sim.profile(False)
+    cnn_ms = None
+    if net is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for k in range(args.steps):
+            net.forward(per_t, "features", out=feats)
+        e1.record(stream)
+        e1.synchronize()
+        cnn_ms = e0.elapsed_time(e1) / args.steps
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -183,12 +212,20 @@ def main():
             "config": {"workload": args.workload, "vessels_per_gpu": V, "rays": R, "circles": C,
                        "polygons": P, "edges_per_polygon": NV, "sensor_range_m": cfg["sensor_range"],
                        "dt_s": cfg["dt"], "lidar": "rasterising, fused k_sense" if fused else "all pairs, 3 kernels",
+                       "cnn": (f"{args.cnn} (features head) on every step's scans, zero-copy" if net is not None
+                               else "none"),
                        "sharding": f"envs x{world}, no data-path collective"},
             "kernel_ms": ({"k_vessel": vessel_s * 1e3, "k_sense": sense_s * 1e3} if fused else
                           {"k_dynamics": vessel_s * 1e3, "k_encounter": enc_s * 1e3, "k_lidar": sense_s * 1e3}),
             "episode_stats": {"done": stats[0].item(), "collisions": stats[1].item(),
                               "reward_sum": stats[2].item(), "envs": stats[3].item()},
         }
+        if cnn_ms is not None:
+            out["kernel_ms"]["k_cnn"] = cnn_ms
+            cb = float(V) * (720 + 4 * net.out_dim("features"))
+            out["roofline_cnn"] = {"kernel": "k_cnn", "bound": "hbm", "achieved": cb / cnn_ms / 1e6,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cb / cnn_ms / 1e6 / HBM_PEAK_GBS,
+                                   "traffic": None, "avg_launch_ms": cnn_ms}
         if fused:
             nbytes = float(sense_bytes_per_env(R, C, P, NV)) * V
             gbs = nbytes / sense_s / 1e9

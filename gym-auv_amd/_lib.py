@@ -37,12 +37,17 @@ BUFFER_NAMES = {
 OPT_LIDAR_MODE, OPT_RASTER_TILE = 0, 1
 LIDAR_RASTER, LIDAR_ALL_PAIRS = 0, 1
 
+# CNN consumers
+CNN_SHALLOW, CNN_2DEEP, CNN_DEEP = 0, 1, 2
+CNN_FEATURES, CNN_RISK = 0, 1
+
 # every symbol include/auvsim.h declares
 EXPORTS = (
     "auv_version", "auv_last_error", "auv_create", "auv_destroy", "auv_set_rays",
     "auv_set_scene", "auv_reset", "auv_step", "auv_step_host", "auv_sense",
     "auv_get_buffer", "auv_read_buffer", "auv_dlpack", "auv_sync", "auv_set_option",
-    "auv_profile_enable",
+    "auv_profile_enable", "auv_cnn_n_weights", "auv_cnn_out_dim", "auv_cnn_create", "auv_cnn_destroy",
+    "auv_cnn_forward", "auv_cnn_last_error",
     "auv_profile_read",
 )
 
@@ -122,5 +127,17 @@ def load():
     lib.auv_profile_enable.argtypes = [vp, i32]
     lib.auv_profile_read.restype = C.c_int
     lib.auv_profile_read.argtypes = [vp, dp, C.POINTER(i64)]
+    lib.auv_cnn_n_weights.restype = C.c_int
+    lib.auv_cnn_n_weights.argtypes = [i32]
+    lib.auv_cnn_out_dim.restype = C.c_int
+    lib.auv_cnn_out_dim.argtypes = [i32, i32]
+    lib.auv_cnn_create.restype = C.c_int
+    lib.auv_cnn_create.argtypes = [i32, vp, i64, C.c_int, C.POINTER(vp)]
+    lib.auv_cnn_destroy.restype = None
+    lib.auv_cnn_destroy.argtypes = [vp]
+    lib.auv_cnn_forward.restype = C.c_int
+    lib.auv_cnn_forward.argtypes = [vp, vp, i64, i32, vp, vp]
+    lib.auv_cnn_last_error.restype = C.c_char_p
+    lib.auv_cnn_last_error.argtypes = [vp]
     _lib = lib
     return lib

@@ -1,0 +1,167 @@
+// Forward passes of the LiDAR-CNN consumers of the scan, fp32, for gfx950.
+//
+// The three reference networks (models/lidar_cnn_shallow.py:23-52,
+// models/lidar_cnn_deep.py:19-96 and :110-157; their RL-side prefixes in
+// radarCNN.py:10-182) are tiny (59 / 178 / 3,723 parameters) and read 720 B
+// per scan, so the pass is HBM-bound: one workgroup takes a tile of scans
+// straight from the simulation's perception buffer, keeps every intermediate
+// activation in LDS, and writes only the 1 / 8 / 12 outputs per scan.
+// 16 lanes cooperate on one scan; weights are read through the scalar/L1 path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace auv {
+
+enum CnnKind { CNN_SHALLOW = 0, CNN_2DEEP = 1, CNN_DEEP = 2 };
+enum CnnHead { HEAD_FEATURES = 0, HEAD_RISK = 1 };
+
+constexpr int kCnnLen = 180;         // scan width the shipped weights were trained on
+constexpr int kCnnLanes = 16;        // lanes per scan
+constexpr int kCnnScans = 16;        // scans per 256-thread workgroup
+constexpr int kCnnBuf = 184;         // floats per activation buffer (>= 180, 16-B multiple)
+
+__host__ __device__ inline int cnn_n_weights(int kind) {
+    return kind == CNN_SHALLOW ? 59 : kind == CNN_2DEEP ? 178 : 3723;
+}
+__host__ __device__ inline int cnn_out_dim(int kind, int head) {
+    if (head == HEAD_RISK) return 1;
+    return kind == CNN_DEEP ? 8 : 12;
+}
+
+struct CnnArgs {
+    const float* scans;  // [B,1,180]
+    const float* w;      // packed state-dict order
+    float* out;          // [B,out_dim]
+    long long B;
+    int kind, head;
+};
+
+// out[co][lo] = act(b[co] + sum_ci sum_k w[co][ci][k] * in[ci][(pos*stride + k - pad) mod L]),
+// optionally followed by MaxPool1d(2, 2, ceil_mode=True) fused into the store
+template <bool RELU, bool POOL>
+__device__ __forceinline__ int conv_layer(const float* in, float* out, const float* w, const float* b, int Cin,
+                                          int Cout, int L, int K, int stride, int pad, int lane) {
+    const int Lc = (L + 2 * pad - K) / stride + 1;
+    const int Lo = POOL ? (Lc + 1) / 2 : Lc;
+    for (int idx = lane; idx < Cout * Lo; idx += kCnnLanes) {
+        const int co = idx / Lo;
+        const int lo = idx - co * Lo;
+        float best = 0.f;
+        const int n_pos = (POOL && 2 * lo + 1 < Lc) ? 2 : 1;
+        for (int j = 0; j < n_pos; ++j) {
+            const int pos = POOL ? 2 * lo + j : lo;
+            float acc = b[co];
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float* wr = w + ((size_t)co * Cin + ci) * K;
+                const float* xr = in + ci * L;
+                int p = pos * stride - pad;
+                p = p < 0 ? p + L : p;
+                for (int k = 0; k < K; ++k) {
+                    acc += wr[k] * xr[p];
+                    p = (p + 1 == L) ? 0 : p + 1;
+                }
+            }
+            if (RELU) acc = acc > 0.f ? acc : 0.f;
+            best = (j == 0 || acc > best) ? acc : best;
+        }
+        out[idx] = best;
+    }
+    return Lo;
+}
+
+template <bool RELU>
+__device__ __forceinline__ void linear_layer(const float* in, float* out, const float* w, const float* b, int n_in,
+                                             int n_out, int lane) {
+    for (int o = lane; o < n_out; o += kCnnLanes) {
+        float acc = 0.f;
+        for (int i = 0; i < n_in; ++i) acc += in[i] * w[(size_t)o * n_in + i];
+        acc += b[o];
+        if (RELU) acc = acc > 0.f ? acc : 0.f;
+        out[o] = acc;
+    }
+}
+
+// the 16 lanes of a scan live in one wave: a wave-level LDS fence is enough
+__device__ __forceinline__ void scan_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+__global__ __launch_bounds__(256) void k_cnn(CnnArgs a) {
+    __shared__ float lds[kCnnScans][3][kCnnBuf];
+    const int tid = threadIdx.x;
+    const long long s0 = (long long)blockIdx.x * kCnnScans;
+    const int ns = (int)((a.B - s0) < kCnnScans ? (a.B - s0) : kCnnScans);
+    // coalesced load of the tile's scans
+    for (int i = tid; i < ns * kCnnLen; i += blockDim.x) {
+        const int s = i / kCnnLen;
+        lds[s][0][i - s * kCnnLen] = a.scans[s0 * kCnnLen + i];
+    }
+    __syncthreads();
+    const int s = tid / kCnnLanes;
+    const int lane = tid - s * kCnnLanes;
+    if (s >= ns) return;
+    float* x = lds[s][0];
+    float* p = lds[s][1];
+    float* q = lds[s][2];
+    const float* w = a.w;
+    float* out = a.out + (s0 + s) * cnn_out_dim(a.kind, a.head);
+    const float* res;
+    int n_res;
+    if (a.kind == CNN_SHALLOW) {
+        // w: conv.weight[45] conv.bias[1] linear.weight[12] linear.bias[1]
+        if (a.head == HEAD_FEATURES) {
+            conv_layer<false, false>(x, p, w, w + 45, 1, 1, kCnnLen, 45, 15, 15, lane);
+            res = p;
+            n_res = 12;
+        } else {
+            conv_layer<true, false>(x, p, w, w + 45, 1, 1, kCnnLen, 45, 15, 15, lane);
+            scan_sync();
+            linear_layer<true>(p, q, w + 46, w + 58, 12, 1, lane);
+            res = q;
+            n_res = 1;
+        }
+    } else if (a.kind == CNN_2DEEP) {
+        // w: c1.w[3*45] c1.b[3] c2.w[2*3*3] c2.b[2] c3.w[1*2*3] c3.b[1] lin.w[12] lin.b[1]
+        conv_layer<true, false>(x, p, w, w + 135, 1, 3, kCnnLen, 45, 15, 15, lane);
+        scan_sync();
+        conv_layer<true, false>(p, q, w + 138, w + 156, 3, 2, 12, 3, 1, 1, lane);
+        scan_sync();
+        conv_layer<false, false>(q, p, w + 158, w + 164, 2, 1, 12, 3, 1, 1, lane);
+        res = p;
+        n_res = 12;
+        if (a.head == HEAD_RISK) {
+            scan_sync();
+            linear_layer<true>(p, q, w + 165, w + 177, 12, 1, lane);
+            res = q;
+            n_res = 1;
+        }
+    } else {
+        // w: c1.w[2*1*9] b[2] c2.w[4*2*9] b[4] c3.w[4*4*9] b[4] c4.w[6*4*9] b[6]
+        //    l1.w[40*72] b[40] l2.w[8*40] b[8] l3.w[8] b[1]
+        int L = conv_layer<true, true>(x, p, w, w + 18, 1, 2, kCnnLen, 9, 1, 4, lane);       // 2 x 90
+        scan_sync();
+        L = conv_layer<true, true>(p, q, w + 20, w + 92, 2, 4, L, 9, 1, 4, lane);            // 4 x 45
+        scan_sync();
+        L = conv_layer<true, true>(q, p, w + 96, w + 240, 4, 4, L, 9, 1, 4, lane);           // 4 x 23
+        scan_sync();
+        L = conv_layer<true, true>(p, q, w + 244, w + 460, 4, 6, L, 9, 1, 4, lane);          // 6 x 12
+        scan_sync();
+        linear_layer<true>(q, p, w + 466, w + 3346, 72, 40, lane);
+        scan_sync();
+        linear_layer<false>(p, q, w + 3386, w + 3706, 40, 8, lane);
+        res = q;
+        n_res = 8;
+        if (a.head == HEAD_RISK) {
+            scan_sync();
+            // ReLU on the 8 features, then Linear(8 -> 1) + ReLU
+            if (lane < 8) p[lane] = q[lane] > 0.f ? q[lane] : 0.f;
+            scan_sync();
+            linear_layer<true>(p, q + 8, w + 3714, w + 3722, 8, 1, lane);
+            res = q + 8;
+            n_res = 1;
+        }
+    }
+    scan_sync();
+    for (int i = lane; i < n_res; i += kCnnLanes) out[i] = res[i];
+}
+
+}  // namespace auv

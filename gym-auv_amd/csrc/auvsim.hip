@@ -16,6 +16,7 @@
 #include "auv_kernels.hpp"
 #include "auv_lidar_raster.hpp"
 #include "auv_sense.hpp"
+#include "auv_cnn.hpp"
 
 using namespace auv;
 
@@ -768,6 +769,97 @@ int auv_profile_read(auv_handle h, double ms[3], int64_t* n_steps) {
     }
     *n_steps = h->prof_steps;
     h->prof_steps = 0;
+    return AUV_OK;
+}
+
+// ---- LiDAR-CNN consumers ----------------------------------------------------
+
+struct auv_cnn {
+    int kind = 0;
+    int device = 0;
+    float* w = nullptr;
+    std::string err;
+};
+
+namespace {
+thread_local std::string g_cnn_error;
+int cnn_fail(auv_cnn* c, int code, const char* fmt, ...) {
+    char tmp[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tmp, sizeof tmp, fmt, ap);
+    va_end(ap);
+    if (c) c->err = tmp; else g_cnn_error = tmp;
+    return code;
+}
+}  // namespace
+
+const char* auv_cnn_last_error(auv_cnn_handle c) { return c ? c->err.c_str() : g_cnn_error.c_str(); }
+
+int auv_cnn_n_weights(int32_t kind) {
+    return (kind < AUV_CNN_SHALLOW || kind > AUV_CNN_DEEP) ? AUV_ERR_ARG : cnn_n_weights(kind);
+}
+
+int auv_cnn_out_dim(int32_t kind, int32_t head) {
+    if (kind < AUV_CNN_SHALLOW || kind > AUV_CNN_DEEP || (head != AUV_CNN_FEATURES && head != AUV_CNN_RISK))
+        return AUV_ERR_ARG;
+    return cnn_out_dim(kind, head);
+}
+
+int auv_cnn_create(int32_t kind, const float* weights, int64_t n_weights, int device, auv_cnn_handle* out) {
+    if (!weights || !out) return cnn_fail(nullptr, AUV_ERR_ARG, "auv_cnn_create: null argument");
+    *out = nullptr;
+    if (kind < AUV_CNN_SHALLOW || kind > AUV_CNN_DEEP)
+        return cnn_fail(nullptr, AUV_ERR_ARG, "auv_cnn_create: unknown network %d", kind);
+    if (n_weights != cnn_n_weights(kind))
+        return cnn_fail(nullptr, AUV_ERR_ARG, "auv_cnn_create: network %d has %d parameters, got %lld", kind,
+                        cnn_n_weights(kind), (long long)n_weights);
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return cnn_fail(nullptr, AUV_ERR_DEVICE, "auv_cnn_create: no HIP device (%s)",
+                        e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= n_dev) return cnn_fail(nullptr, AUV_ERR_ARG, "auv_cnn_create: device %d out of range", device);
+    if (hipSetDevice(device) != hipSuccess) return cnn_fail(nullptr, AUV_ERR_DEVICE, "hipSetDevice failed");
+    auv_cnn* c = new auv_cnn();
+    c->kind = kind;
+    c->device = device;
+    if (hipMalloc((void**)&c->w, (size_t)n_weights * sizeof(float)) != hipSuccess ||
+        hipMemcpy(c->w, weights, (size_t)n_weights * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        if (c->w) (void)hipFree(c->w);
+        delete c;
+        return cnn_fail(nullptr, AUV_ERR_MEMORY, "auv_cnn_create: weight upload failed");
+    }
+    *out = c;
+    return AUV_OK;
+}
+
+void auv_cnn_destroy(auv_cnn_handle c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->w) (void)hipFree(c->w);
+    delete c;
+}
+
+int auv_cnn_forward(auv_cnn_handle c, const float* scans, int64_t n_scans, int32_t head, float* out, void* stream) {
+    if (!c) return AUV_ERR_ARG;
+    if (!scans || !out) return cnn_fail(c, AUV_ERR_ARG, "auv_cnn_forward: null argument");
+    if (head != AUV_CNN_FEATURES && head != AUV_CNN_RISK) return cnn_fail(c, AUV_ERR_ARG, "auv_cnn_forward: unknown head %d", head);
+    if (n_scans < 0 || n_scans > ((int64_t)1 << 31) * kCnnScans / 2)
+        return cnn_fail(c, AUV_ERR_ARG, "auv_cnn_forward: bad scan count %lld", (long long)n_scans);
+    if (n_scans == 0) return AUV_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return cnn_fail(c, AUV_ERR_DEVICE, "hipSetDevice failed");
+    CnnArgs a;
+    a.scans = scans;
+    a.w = c->w;
+    a.out = out;
+    a.B = n_scans;
+    a.kind = c->kind;
+    a.head = head;
+    const unsigned blocks = (unsigned)((n_scans + kCnnScans - 1) / kCnnScans);
+    hipLaunchKernelGGL(k_cnn, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cnn_fail(c, AUV_ERR_DEVICE, "k_cnn launch failed: %s", hipGetErrorString(e));
     return AUV_OK;
 }
 

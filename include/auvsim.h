@@ -178,6 +178,35 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value);
 int auv_profile_enable(auv_handle h, int32_t on);
 int auv_profile_read(auv_handle h, double ms[3], int64_t* n_steps);
 
+/* ---- LiDAR-CNN consumers of the scan (fp32, 180-ray scans) -----------------
+ * Forward passes of the three reference networks, reading the perception
+ * buffer in place.  Weights: the network's state dict, tensors flattened and
+ * concatenated in state-dict order (59 / 178 / 3,723 floats).
+ *   AUV_CNN_SHALLOW  models/lidar_cnn_shallow.py:23-52; features head =
+ *                    LidarCNN_shallow_pretrained, radarCNN.py:165-182 (12)
+ *   AUV_CNN_2DEEP    models/lidar_cnn_deep.py:110-157; features head =
+ *                    LidarCNN_not_so_deep_pretrained, radarCNN.py:110-146 (12)
+ *   AUV_CNN_DEEP     models/lidar_cnn_deep.py:19-96 with channels [2,4,4,6],
+ *                    kernel 9 (trainer.py:144); features head =
+ *                    LidarCNN_deep_pretrained, radarCNN.py:25-94 (8)
+ * AUV_CNN_RISK is the full network of models/ (one risk value per scan). */
+typedef struct auv_cnn* auv_cnn_handle;
+#define AUV_CNN_SHALLOW 0
+#define AUV_CNN_2DEEP 1
+#define AUV_CNN_DEEP 2
+#define AUV_CNN_FEATURES 0
+#define AUV_CNN_RISK 1
+
+int auv_cnn_n_weights(int32_t kind);              /* parameter count, or AUV_ERR_ARG */
+int auv_cnn_out_dim(int32_t kind, int32_t head);  /* outputs per scan, or AUV_ERR_ARG */
+int auv_cnn_create(int32_t kind, const float* weights /* host */, int64_t n_weights, int device,
+                   auv_cnn_handle* out);
+void auv_cnn_destroy(auv_cnn_handle c);
+/* scans: DEVICE f32 [n_scans,1,180]; out: DEVICE f32 [n_scans,out_dim].  Asynchronous on `stream`. */
+int auv_cnn_forward(auv_cnn_handle c, const float* scans, int64_t n_scans, int32_t head, float* out,
+                    void* stream);
+const char* auv_cnn_last_error(auv_cnn_handle c);
+
 #ifdef __cplusplus
 }
 #endif

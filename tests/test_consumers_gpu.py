@@ -1,0 +1,77 @@
+"""HIP forward passes of the LiDAR CNNs against the reference-generated golden
+outputs and the numpy oracle, and the zero-copy hand-off of a live scan."""
+import os
+
+import numpy as np
+import pytest
+
+from gym_auv_amd import cnn, scenarios
+from oracle import cnn_oracle as N
+from tests.helpers import make_sim
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "cnn_golden.npz")
+TOL = 5e-6   # fp32; summation order differs from torch's CPU kernels
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.mark.parametrize("tag", ["shallow", "deep2", "deep"])
+@pytest.mark.parametrize("head", ["risk", "features"])
+def test_hip_cnn_matches_reference_golden(gold, tag, head):
+    import torch
+
+    net = cnn.LidarCNN(tag, N.golden_weights(gold, tag))
+    x = torch.from_numpy(gold["x"]).cuda()
+    y = net(x, head).cpu().numpy()
+    ref = gold[f"{tag}_{head}"]
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= TOL, np.abs(y - ref).max()
+    net.close()
+
+
+@pytest.mark.parametrize("tag", ["shallow", "deep2", "deep"])
+def test_hip_cnn_ragged_batches_against_oracle(gold, tag):
+    import torch
+
+    W = N.golden_weights(gold, tag)
+    net = cnn.LidarCNN(tag, W)
+    rng = np.random.default_rng(3)
+    for B in (1, 15, 16, 17, 1000, 4099):
+        x = rng.uniform(0, 1, (B, 1, 180)).astype(np.float32)
+        for head in ("risk", "features"):
+            y = net(torch.from_numpy(x).cuda(), head).cpu().numpy()
+            assert np.abs(y - N.MODELS[tag](x, W, head)).max() <= TOL
+    assert net(torch.empty((0, 1, 180), dtype=torch.float32, device="cuda")).shape == (0, 1)
+    net.close()
+
+
+def test_scan_feeds_cnn_zero_copy(gold):
+    """cfg3's hand-off: the perception buffer written by k_sense is read in
+    place by the shallow CNN; features + navigation = the extractor output of
+    radarCNN.py:270-280."""
+    import torch
+
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=2048)
+    sim = make_sim(cfg, scene)
+    st = torch.cuda.current_stream()
+    sim.reset(scene["init_state"], stream=st)
+    obs = {"perception": sim.tensor("perception"), "navigation": sim.tensor("navigation")}
+    W = N.golden_weights(gold, "shallow")
+    ext = cnn.PerceptionNavigationExtractor("shallow", W)
+    assert ext.features_dim == 18
+    acts = torch.from_numpy(scenarios.random_actions(2048, 3, seed=8)).cuda()
+    for k in range(3):
+        sim.step_device(acts[k].data_ptr(), stream=st)
+        feats = ext(obs)
+        risk = ext.cnn(obs["perception"], "risk")
+        st.synchronize()
+        scans = sim.read("perception")
+        assert obs["perception"].data_ptr() == sim.buffer("perception")[0]
+        assert np.abs(feats[:, :12].cpu().numpy() - N.shallow(scans, W, "features")).max() <= TOL
+        assert np.array_equal(feats[:, 12:].cpu().numpy(), sim.read("navigation")[:, 0, :])
+        assert np.abs(risk.cpu().numpy() - N.shallow(scans, W, "risk")).max() <= TOL
+    sim.close()
