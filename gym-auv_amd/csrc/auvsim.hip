@@ -772,6 +772,25 @@ int auv_profile_read(auv_handle h, double ms[3], int64_t* n_steps) {
     return AUV_OK;
 }
 
+// ---- dataset text rows (host only) ------------------------------------------
+
+int64_t auv_format_rows(const double* values, const int32_t* row_len, int64_t n_rows, int64_t stride, char* out,
+                        int64_t out_cap) {
+    if (!values || !row_len || !out || n_rows < 0 || stride < 0) return AUV_ERR_ARG;
+    int64_t pos = 0;
+    for (int64_t i = 0; i < n_rows; ++i) {
+        const double* row = values + i * stride;
+        for (int32_t j = 0; j < row_len[i]; ++j) {
+            if (out_cap - pos < 32) return AUV_ERR_MEMORY;
+            if (j) out[pos++] = ' ';
+            pos += snprintf(out + pos, 30, "%.18e", row[j]);
+        }
+        if (out_cap - pos < 2) return AUV_ERR_MEMORY;
+        out[pos++] = '\n';
+    }
+    return pos;
+}
+
 // ---- LiDAR-CNN consumers ----------------------------------------------------
 
 struct auv_cnn {

@@ -1,0 +1,186 @@
+"""The LiDAR-risk dataset: writing rows from a running simulation in the
+reference's three text formats, and loading them back the way the
+reference's trainer does.
+
+Formats (numpy.savetxt defaults, "%.18e", space separated), one row per
+logged sample, the three files row-aligned:
+  LiDAR_<name>.csv     180 ranges in metres           (utils/dataloader.py:55-56)
+  risk_<name>.csv      one risk per tracked obstacle  (utils/dataloader.py:108)
+  metadata_<name>.csv  speed_OS heading_OS then (heading_ts dist speed bearing
+                       course) per tracked obstacle   (utils/explore_dataset.py:8,40-53)
+A sample is logged only when at least one obstacle is tracked (every shipped
+row has one); an obstacle is tracked when its slot is in use and its hull
+distance is below the sensor range.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+N_SENSORS = 180       # utils/dataloader.py:13
+SENSOR_RANGE = 150.0  # utils/dataloader.py:56
+
+
+# ----------------------------------------------------------------------------
+# writing
+# ----------------------------------------------------------------------------
+def format_rows(values: np.ndarray, row_len=None) -> bytes:
+    """Text of ragged rows: row i = values[i, :row_len[i]] (all columns when
+    row_len is None).  Formatting runs in the native library."""
+    lib = _lib.load()
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    if values.ndim != 2:
+        raise ValueError("values must be 2-D")
+    n, stride = values.shape
+    if row_len is None:
+        row_len = np.full(n, stride, dtype=np.int32)
+    row_len = np.ascontiguousarray(row_len, dtype=np.int32)
+    if row_len.shape != (n,) or (row_len > stride).any() or (row_len < 0).any():
+        raise ValueError("row_len")
+    cap = int(row_len.sum()) * 27 + n + 64
+    buf = C.create_string_buffer(cap)
+    got = lib.auv_format_rows(values.ctypes.data_as(C.c_void_p), row_len.ctypes.data_as(C.c_void_p), n, stride,
+                              buf, cap)
+    if got < 0:
+        raise _lib.AuvError(int(got), "auv_format_rows")
+    return buf.raw[:got]
+
+
+class DatasetWriter:
+    """Appends row-aligned samples to LiDAR_/risk_/metadata_<name>.csv."""
+
+    def __init__(self, directory: str, name: str = "MovingObstaclesNoRules"):
+        os.makedirs(directory, exist_ok=True)
+        self.paths = {k: os.path.join(directory, f"{k}_{name}.csv") for k in ("LiDAR", "risk", "metadata")}
+        self._f = {k: open(p, "ab") for k, p in self.paths.items()}
+        self.rows = 0
+
+    def write(self, ranges, own, meta, risk, tracked):
+        """ranges [n,R], own [n,2], meta [n,O,5], risk [n,O], tracked bool [n,O].
+        Samples without a tracked obstacle are skipped.  Returns rows written."""
+        tracked = np.asarray(tracked, dtype=bool)
+        keep = tracked.any(axis=1)
+        if not keep.any():
+            return 0
+        ranges, own = np.asarray(ranges)[keep], np.asarray(own)[keep]
+        meta, risk, tracked = np.asarray(meta)[keep], np.asarray(risk)[keep], tracked[keep]
+        n, O = tracked.shape
+        cnt = tracked.sum(axis=1).astype(np.int32)
+        # compact the tracked obstacles of each sample to the front, id order kept
+        order = np.argsort(~tracked, axis=1, kind="stable")
+        risk_c = np.take_along_axis(risk, order, axis=1)
+        meta_c = np.take_along_axis(meta, order[:, :, None], axis=1).reshape(n, O * 5)
+        self._f["LiDAR"].write(format_rows(ranges))
+        self._f["risk"].write(format_rows(risk_c, cnt))
+        self._f["metadata"].write(format_rows(np.concatenate([own, meta_c], axis=1), 2 + 5 * cnt))
+        self.rows += n
+        return n
+
+    def close(self):
+        for f in self._f.values():
+            f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class DatasetLogger:
+    """Logs every `every`-th step of an `AuvSim` (the shipped rows are about
+    5 s of simulated time apart)."""
+
+    def __init__(self, sim, writer: DatasetWriter, every: int = 5):
+        self.sim, self.writer, self.every = sim, writer, int(every)
+        self._k = 0
+
+    def after_step(self, stream=None):
+        self._k += 1
+        if self._k % self.every:
+            return 0
+        sim = self.sim
+        dist = sim.read("obst_dist", stream)
+        tracked = np.isfinite(dist) & (dist < sim.cfg["sensor_range"])
+        return self.writer.write(sim.read("ranges", stream), sim.read("own", stream), sim.read("meta", stream),
+                                 sim.read("risk", stream), tracked)
+
+
+def save_binary(path, ranges, own, meta, risk, tracked):
+    """Compact sink for large regenerations; `export_csv` turns it into the text files."""
+    np.savez_compressed(path, ranges=ranges, own=own, meta=meta, risk=risk, tracked=tracked)
+
+
+def export_csv(npz_path, directory, name="MovingObstaclesNoRules"):
+    d = np.load(npz_path)
+    with DatasetWriter(directory, name) as w:
+        return w.write(d["ranges"], d["own"], d["meta"], d["risk"], d["tracked"])
+
+
+# ----------------------------------------------------------------------------
+# reading (what the reference's trainer does with the files)
+# ----------------------------------------------------------------------------
+def read_ragged(path):
+    """List of float64 arrays, one per non-empty line."""
+    with open(path) as f:
+        return [np.array(line.split(), dtype=np.float64) for line in f if line.strip()]
+
+
+def parse_metadata_row(row):
+    """(speed_OS, heading_OS, records [n,5]) of one metadata row
+    (utils/explore_dataset.py:40-45)."""
+    n = (len(row) - 2) // 5
+    return row[0], row[1], np.asarray(row[2:2 + 5 * n]).reshape(n, 5)
+
+
+def is_static(record, speed_os):
+    """The reference's static-obstacle test (utils/explore_dataset.py:46)."""
+    return record[0] == 0 and record[2] == speed_os
+
+
+def calculate_total_risk(path_y, mode):
+    """Label per sample from its per-obstacle risks: 'max', 'sum', else the
+    mean, over at most 8 columns, absent columns skipped
+    (utils/dataloader.py:104-120)."""
+    rows = read_ragged(path_y)
+    out = np.empty(len(rows))
+    for i, r in enumerate(rows):
+        r = r[:8]
+        out[i] = r.max() if mode == "max" else r.sum() if mode == "sum" else r.mean()
+    return out
+
+
+def prev_timesteps_feature_engineering(X, time_steps):
+    """Stack the k previous scans behind each scan, [n,R] -> [n,R,k+1]; history
+    before the first row is an empty scan of 150 m (utils/dataloader.py:123-134)."""
+    X = np.asarray(X, dtype=np.float64)
+    out = [X]
+    prev = X
+    for _ in range(time_steps):
+        prev = np.concatenate([np.full((1, X.shape[1]), SENSOR_RANGE), prev[:-1]], axis=0)
+        out.append(prev)
+    return np.stack(out, axis=2)
+
+
+def split_sizes(n, train_test_split=0.7, train_val_split=0.2):
+    """(train, val, test) sizes of the sequential split (utils/dataloader.py:63-67)."""
+    train = int(train_test_split * n)
+    val = int(train_val_split * train)
+    return train - val, val, n - train
+
+
+def load_lidar_dataset(path_x, path_y, mode=None, train_test_split=0.7, train_val_split=0.2):
+    """Arrays of the three splits as the reference builds them
+    (utils/dataloader.py:44-101): X = 1 - X/150 with a channel dimension,
+    float32; y reduced by `mode` (None: the file holds one label per row)."""
+    X = 1.0 - np.loadtxt(path_x) / SENSOR_RANGE
+    y = np.loadtxt(path_y) if mode is None else calculate_total_risk(path_y, mode)
+    n_train, n_val, n_test = split_sizes(len(X), train_test_split, train_val_split)
+    sl = {"train": slice(0, n_train), "val": slice(n_train, n_train + n_val), "test": slice(len(X) - n_test, len(X))}
+    out = {k: (X[s].astype(np.float32)[:, None, :], y[s].astype(np.float32)[:, None]) for k, s in sl.items()}
+    out["x_mean"], out["x_std"] = X[:n_train].mean(), X[:n_train].std()
+    return out

@@ -178,6 +178,16 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value);
 int auv_profile_enable(auv_handle h, int32_t on);
 int auv_profile_read(auv_handle h, double ms[3], int64_t* n_steps);
 
+/* ---- dataset text rows (host only, no GPU involved) -------------------------
+ * Formats n_rows ragged rows of doubles as the reference's dataset files do
+ * (numpy.savetxt defaults: "%.18e", single spaces, "\n"; the files read by
+ * utils/dataloader.py:55,59,108 and utils/explore_dataset.py:39).  Row i holds
+ * row_len[i] values starting at values[i*stride].  Returns the number of bytes
+ * written to `out`, AUV_ERR_MEMORY if out_cap is too small (27 bytes per value
+ * + 1 per row always suffice), AUV_ERR_ARG on a null pointer. */
+int64_t auv_format_rows(const double* values, const int32_t* row_len, int64_t n_rows, int64_t stride,
+                        char* out, int64_t out_cap);
+
 /* ---- LiDAR-CNN consumers of the scan (fp32, 180-ray scans) -----------------
  * Forward passes of the three reference networks, reading the perception
  * buffer in place.  Weights: the network's state dict, tensors flattened and

@@ -1,0 +1,88 @@
+"""Dataset rows: the text format and the loader-side arithmetic, pinned by
+the reference's shipped files (tests/golden/*_rows.csv are their first 300
+rows; dataset_golden.npz holds what the reference's own utils/dataloader.py
+computes on them, see tests/golden/make_dataset_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from gym_auv_amd import dataset as D
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(G, "dataset_golden.npz"))
+
+
+def test_formatter_reproduces_shipped_rows_byte_for_byte(lib):
+    for name in ("risk", "metadata"):
+        path = os.path.join(G, f"{name}_rows.csv")
+        raw = open(path, "rb").read()
+        rows = D.read_ragged(path)
+        width = max(len(r) for r in rows)
+        vals = np.zeros((len(rows), width))
+        lens = np.array([len(r) for r in rows], dtype=np.int32)
+        for i, r in enumerate(rows):
+            vals[i, :len(r)] = r
+        assert D.format_rows(vals, lens) == raw
+
+
+def test_formatter_matches_numpy_savetxt(tmp_path):
+    x = np.random.default_rng(0).normal(size=(13, 180)) * 1e3
+    x[0, 0], x[1, 1], x[2, 2] = 0.0, -0.0, 150.0
+    p = tmp_path / "a.csv"
+    np.savetxt(p, x)
+    assert D.format_rows(x) == p.read_bytes()
+    assert D.format_rows(np.zeros((0, 5))) == b""
+
+
+def test_metadata_rows_are_aligned_with_risk_rows():
+    meta = D.read_ragged(os.path.join(G, "metadata_rows.csv"))
+    risk = D.read_ragged(os.path.join(G, "risk_rows.csv"))
+    assert len(meta) == len(risk) == 300
+    for m, r in zip(meta, risk):
+        speed, heading, rec = D.parse_metadata_row(m)
+        assert len(rec) == len(r) >= 1
+        assert all(D.is_static(q, speed) == (q[0] == 0 and q[2] == speed) for q in rec)
+
+
+@pytest.mark.parametrize("mode", ["max", "sum", "mean"])
+def test_risk_reduction_matches_reference_loader(gold, mode):
+    y = D.calculate_total_risk(os.path.join(G, "risk_rows.csv"), mode)
+    assert np.allclose(y, gold[f"label_{mode}"], rtol=1e-15, atol=0)
+
+
+def test_prev_timesteps_and_split_match_reference(gold):
+    assert np.array_equal(D.prev_timesteps_feature_engineering(gold["prev_in"], 3), gold["prev_out"])
+    n, tr, va, te = gold["split_full"]
+    # trainer.py:120-125 calls the loader with train_test_split 0.7 and train_val_split 0.3
+    assert D.split_sizes(int(n), 0.7, 0.3) == (tr, va, te) == (4937, 2115, 3023)
+
+
+def test_writer_round_trip(tmp_path):
+    rng = np.random.default_rng(1)
+    n, O = 6, 4
+    ranges = rng.uniform(0, 150, (n, 180))
+    own = rng.normal(size=(n, 2))
+    meta = rng.normal(size=(n, O, 5))
+    risk = rng.uniform(0, 1, (n, O))
+    tracked = rng.random((n, O)) < 0.5
+    tracked[0] = False              # a sample nobody tracks is not logged
+    tracked[1] = True
+    with D.DatasetWriter(str(tmp_path), "t") as w:
+        assert w.write(ranges, own, meta, risk, tracked) == int(tracked.any(1).sum())
+    keep = tracked.any(1)
+    X = np.loadtxt(w.paths["LiDAR"]).reshape(-1, 180)
+    assert np.array_equal(X, ranges[keep])
+    rr = D.read_ragged(w.paths["risk"])
+    mm = D.read_ragged(w.paths["metadata"])
+    for row_r, row_m, i in zip(rr, mm, np.nonzero(keep)[0]):
+        assert np.array_equal(row_r, risk[i][tracked[i]])
+        s, h, rec = D.parse_metadata_row(row_m)
+        assert (s, h) == tuple(own[i]) and np.array_equal(rec, meta[i][tracked[i]])
+    out = D.load_lidar_dataset(w.paths["LiDAR"], w.paths["risk"], mode="max")
+    assert out["train"][0].shape[1:] == (1, 180) and out["train"][0].dtype == np.float32
+    assert np.allclose(out["test"][0][-1, 0], 1 - ranges[keep][-1] / 150, atol=1e-7)
