@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--tile", type=int, default=0, help="envs per k_sense workgroup, 0 = auto")
     ap.add_argument("--cnn", default="shallow", choices=["none", "shallow", "deep2", "deep"],
                     help="LiDAR CNN fed zero-copy with every step's scans (features head)")
+    ap.add_argument("--gather-scans", action="store_true",
+                    help="also gather the final scans of every rank on rank 0 once per rollout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=60)
@@ -87,6 +89,7 @@ def main():
     import torch.distributed as dist
 
     from gym_auv_amd import _lib, scenarios
+    from gym_auv_amd import dist as auv_dist
     from gym_auv_amd.sim import AuvSim
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,6 +117,8 @@ def main():
     acts = torch.from_numpy(scenarios.random_actions(V, n_act, seed=100 + rank)).to(dev)
     ptrs = [acts[i].data_ptr() for i in range(n_act)]
     done_t, coll_t, rew_t = sim.tensor("done"), sim.tensor("collision"), sim.tensor("reward")
+    goal_t, trunc_t = sim.tensor("reached_goal"), sim.tensor("truncated")
+    per_all = sim.tensor("perception")
 
     # the consumer of the scans: the reference's shipped weights (fixture made from its own files)
     net = feats = per_t = None
@@ -136,12 +141,14 @@ def main():
             torch.cuda.synchronize(dev)
 
     def episode_stats():
-        # episode statistics of a rollout: one small all-reduce, not per step
-        stats = torch.stack([done_t.sum(dtype=torch.float64), coll_t.sum(dtype=torch.float64),
-                             rew_t.sum(), torch.tensor(float(V), device=dev, dtype=torch.float64)])
-        if world > 1:
-            dist.all_reduce(stats)
-        return stats
+        # episode statistics of a rollout: one small all-reduce (RCCL), not per step;
+        # optionally the last scans of every rank gathered on the trainer rank 0
+        st = auv_dist.EpisodeStats(dev)
+        st.update(done_t, coll_t, goal_t, trunc_t, rew_t)
+        totals = st.reduce()
+        if args.gather_scans and per_all is not None:
+            auv_dist.gather_scans(per_all, dst=0)
+        return totals
 
     def rollout():
         for k in range(args.steps):
@@ -217,8 +224,7 @@ def main():
                        "sharding": f"envs x{world}, no data-path collective"},
             "kernel_ms": ({"k_vessel": vessel_s * 1e3, "k_sense": sense_s * 1e3} if fused else
                           {"k_dynamics": vessel_s * 1e3, "k_encounter": enc_s * 1e3, "k_lidar": sense_s * 1e3}),
-            "episode_stats": {"done": stats[0].item(), "collisions": stats[1].item(),
-                              "reward_sum": stats[2].item(), "envs": stats[3].item()},
+            "episode_stats": stats,
         }
         if cnn_ms is not None:
             out["kernel_ms"]["k_cnn"] = cnn_ms

@@ -1,0 +1,90 @@
+"""Multi-GPU layer: one process per GPU, envs sharded in contiguous blocks.
+
+Stepping needs no communication (envs are independent).  Two collectives
+exist, both outside the per-step path:
+  * `reduce_episode_stats`: one all-reduce(sum) of a small statistics vector
+    per rollout (64 B; latency-bound, so never per step);
+  * `gather_scans`: the scans of every rank to one trainer rank.  A gather is
+    peer-to-peer writes into the trainer, which on xGMI uses all of the
+    trainer's inbound links in parallel; a ring all-gather would be bound by
+    one link.
+The backend is whatever the process group was created with: "nccl" (= RCCL
+over xGMI) on GPUs, "gloo" in the CPU tests.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+STAT_FIELDS = ("env_steps", "episodes_done", "collisions", "goals", "truncations", "reward_sum",
+               "min_range_sum", "risk_max_sum")
+
+
+def shard_range(n_total: int, rank: int, world: int):
+    """Contiguous block [begin, end) of envs owned by `rank`; sizes differ by at most one."""
+    base, rem = divmod(int(n_total), int(world))
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def shard_scene(scene: dict, rank: int, world: int) -> dict:
+    """This rank's slice of a full-size scene dict."""
+    n = scene["path"].shape[0]
+    b, e = shard_range(n, rank, world)
+    return {k: (v[:, b:e] if k == "init_state" else v[b:e]) for k, v in scene.items()}
+
+
+class EpisodeStats:
+    """Running episode statistics of one rank, kept on the device of its
+    tensors; `reduce()` returns the node-wide totals as a dict."""
+
+    def __init__(self, device):
+        self.vec = torch.zeros(len(STAT_FIELDS), dtype=torch.float64, device=device)
+
+    def update(self, done, collision, reached_goal, truncated, reward, ranges=None, risk=None):
+        """Accumulate one step's outputs (tensors of this rank's envs)."""
+        n = done.numel()
+        f64 = torch.float64
+        parts = [torch.tensor(float(n), dtype=f64, device=self.vec.device), done.sum(dtype=f64),
+                 collision.sum(dtype=f64), reached_goal.sum(dtype=f64), truncated.sum(dtype=f64),
+                 reward.sum(dtype=f64),
+                 ranges.amin(dim=-1).sum(dtype=f64) if ranges is not None else self.vec.new_zeros(()),
+                 risk.amax(dim=-1).sum(dtype=f64) if risk is not None else self.vec.new_zeros(())]
+        self.vec += torch.stack(parts)
+
+    def reduce(self, group=None) -> dict:
+        return reduce_episode_stats(self.vec, group)
+
+
+def reduce_episode_stats(vec: torch.Tensor, group=None) -> dict:
+    """all-reduce(sum) of the statistics vector over all ranks."""
+    total = vec.clone()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    return dict(zip(STAT_FIELDS, total.tolist()))
+
+
+def gather_scans(perception: torch.Tensor, dst: int = 0, group=None):
+    """Gather every rank's scans `[V_local,1,R]` on rank `dst`, in rank order
+    (= env order of the block sharding).  Returns `[V_total,1,R]` on `dst`,
+    None elsewhere.  Shards may differ in size by one env."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return perception
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = torch.zeros(world, dtype=torch.int64, device=perception.device)
+    sizes[rank] = perception.shape[0]
+    dist.all_reduce(sizes, group=group)
+    sizes = sizes.tolist()
+    vmax = max(sizes)
+    send = perception
+    if perception.shape[0] < vmax:   # gather needs equal shapes: pad the short shards
+        pad = perception.new_zeros((vmax - perception.shape[0],) + tuple(perception.shape[1:]))
+        send = torch.cat([perception, pad], dim=0)
+    send = send.contiguous()
+    if rank == dst:
+        bufs = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, bufs, dst=dst, group=group)
+        return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
+    dist.gather(send, None, dst=dst, group=group)
+    return None

@@ -1,0 +1,100 @@
+"""The N > 1 path on CPU: world_size-2 gloo process group, block sharding of
+envs, the rollout statistics all-reduce and the scan gather.  Each rank steps
+its own shard with the CPU oracle (no GPU here); the union must equal a
+single-process run of the whole batch, bit for bit, because envs never
+interact."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as tdist
+import torch.multiprocessing as mp
+
+from gym_auv_amd import dist as D
+from gym_auv_amd import scenarios
+from tests.helpers import make_oracle
+
+V, STEPS = 37, 4     # odd on purpose: shards of 19 and 18
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_shard(cfg, scene, acts):
+    env = make_oracle(cfg, scene)
+    env.reset(scene["init_state"])
+    stats = D.EpisodeStats("cpu")
+    for k in range(STEPS):
+        env.step(acts[k])
+        stats.update(torch.from_numpy(env.done), torch.from_numpy(env.collision),
+                     torch.from_numpy(env.reached_goal), torch.from_numpy(env.truncated),
+                     torch.from_numpy(env.reward), torch.from_numpy(env.ranges), torch.from_numpy(env.risk))
+    return env, stats
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=V)
+        acts = scenarios.random_actions(V, STEPS, seed=3)
+        b, e = D.shard_range(V, rank, world)
+        env, stats = _run_shard(dict(cfg, n_envs=e - b), D.shard_scene(scene, rank, world), acts[:, :, b:e])
+        totals = stats.reduce()
+        scans = D.gather_scans(torch.from_numpy(env.perception), dst=0)
+        if rank == 0:
+            q.put((totals, scans.numpy()))
+        else:
+            assert scans is None
+            q.put((totals, None))
+    finally:
+        tdist.destroy_process_group()
+
+
+def test_shard_ranges_partition():
+    for n in (1, 7, 64, 65536 * 8 + 3):
+        for w in (1, 2, 3, 8):
+            r = [D.shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [e - b for b, e in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_rollout_equals_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=V)
+    env, stats = _run_shard(cfg, scene, scenarios.random_actions(V, STEPS, seed=3))
+    want = dict(zip(D.STAT_FIELDS, stats.vec.tolist()))
+    scans = [s for _, s in got if s is not None]
+    assert len(scans) == 1 and np.array_equal(scans[0], env.perception)
+    for totals, _ in got:            # every rank holds the node-wide totals
+        assert totals["env_steps"] == V * STEPS
+        for k in D.STAT_FIELDS:
+            assert totals[k] == pytest.approx(want[k], rel=1e-12)
+
+
+def test_single_process_paths_need_no_group():
+    x = torch.rand(5, 1, 180)
+    assert D.gather_scans(x) is x
+    s = D.EpisodeStats("cpu")
+    z = torch.zeros(5, dtype=torch.uint8)
+    s.update(z, z, z, z, torch.ones(5, dtype=torch.float64))
+    assert s.reduce()["reward_sum"] == 5.0
