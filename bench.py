@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--envs", type=int, default=None, help="override vessels per GPU")
     ap.add_argument("--lidar-mode", type=int, default=0, help="0 rasterising (default), 1 all pairs")
     ap.add_argument("--tile", type=int, default=0, help="envs per k_sense workgroup, 0 = auto")
+    ap.add_argument("--block", type=int, default=0, help="threads per k_sense workgroup (64/128/256), 0 = default")
     ap.add_argument("--cnn", default="shallow", choices=["none", "shallow", "deep2", "deep"],
                     help="LiDAR CNN fed zero-copy with every step's scans (features head)")
     ap.add_argument("--gather-scans", action="store_true",
@@ -109,6 +110,8 @@ def main():
     sim.set_option(_lib.OPT_LIDAR_MODE, args.lidar_mode)
     if args.tile:
         sim.set_option(_lib.OPT_RASTER_TILE, args.tile)
+    if args.block:
+        sim.set_option(_lib.OPT_SENSE_BLOCK, args.block)
     sim.set_scene(scene)
     stream = torch.cuda.current_stream(dev)
     sim.reset(scene["init_state"], stream=stream)

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libauvsim.so")
+# AUVSIM_LIB points diagnostic runs at another build of the same library
+LIB_PATH = os.environ.get("AUVSIM_LIB") or os.path.join(_HERE, "libauvsim.so")
 
 ABI_VERSION = 1
 N_MODEL = 16
@@ -34,7 +35,7 @@ BUFFER_NAMES = {
 }
 
 # auv_option
-OPT_LIDAR_MODE, OPT_RASTER_TILE = 0, 1
+OPT_LIDAR_MODE, OPT_RASTER_TILE, OPT_SENSE_BLOCK = 0, 1, 2
 LIDAR_RASTER, LIDAR_ALL_PAIRS = 0, 1
 
 # CNN consumers

@@ -154,7 +154,7 @@ __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P,
     return L;
 }
 
-enum ObstRec { OB_MX = 0, OB_MY, OB_RVX, OB_RVY, OB_BEARING, OB_COURSE, OB_DIST, OB_COUNT = 8 };
+enum ObstRec { OB_MX = 0, OB_MY, OB_RVX, OB_RVY, OB_X, OB_Y, OB_DIST, OB_HEADING, OB_COUNT = 8 };
 
 // One (primitive, ray) pair of the dense list: decode, build the ray, run the
 // exact test.  `slot` = accumulator index of the ray, `oid` = obstacle id.
@@ -212,6 +212,36 @@ __device__ __forceinline__ double risk_index(double mx, double my, double rvx, d
     return inrange ? rr : 0.0;
 }
 
+// per-env outputs that need the scene: nearest obstacle, collision, reward, done
+__device__ __forceinline__ void env_summary(const SenseArgs& a, int e, double bd, int bi) {
+    const uint8_t coll = bd < 0.0 ? 1 : 0;
+    const uint8_t goal = a.reached_goal[e];
+    a.min_dist[e] = bd;
+    a.min_idx[e] = bi;
+    a.collision[e] = coll;
+    double rew = 0.0;
+    if (a.is_step) {
+        rew = a.envrec[(size_t)e * ER_COUNT + ER_REWARD];
+        rew = rew - (coll ? a.rw_collision : 0.0);
+        rew = rew + (goal ? a.rw_goal : 0.0);
+    }
+    a.reward[e] = rew;
+    a.done[e] = coll | goal | a.truncated[e];
+}
+
+// Diagnostic builds (-DAUV_PHASE_STAMPS) record the shader clock of every wave
+// at the phase boundaries of k_sense; the product build compiles these away.
+#ifdef AUV_PHASE_STAMPS
+__device__ long long* g_stamps = nullptr;
+#define AUV_STAMP(n)                                                                                  \
+    do {                                                                                              \
+        if (g_stamps && (threadIdx.x & 63) == 0)                                                      \
+            g_stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (n)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define AUV_STAMP(n)
+#endif
+
 constexpr int kKeep = 4;  // pair-list passes whose hit keys stay in registers between the two sweeps
 
 __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
@@ -243,6 +273,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
     const float inv_delta = (float)R * (1.0f / 6.2831853f);
     const float half_scan = 0.5f * (float)R;
 
+    AUV_STAMP(0);
     // ---- phase 1: per-ray accumulators, heading sin/cos, primitives.  Nothing
     // here reads LDS written by another thread, so no barrier is needed before.
     for (int el = tid; el < ne; el += nthr) {
@@ -329,6 +360,9 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
             ob[OB_MY] = Y - py;
             ob[OB_RVX] = pvx - er[ER_VOX];
             ob[OB_RVY] = pvy - er[ER_VOY];
+            ob[OB_X] = X;  // advanced position, written back in phase 2
+            ob[OB_Y] = Y;
+            ob[OB_HEADING] = a.poly_heading[ep];
         }
         double ax = 0.0, ay = 0.0, ex = 0.0, ey = 0.0, nt = 0.0, dd = __builtin_inf();
         int cross = 0;
@@ -390,10 +424,12 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         sg[3] = ey;
         sg[4] = nt;
         edist[i] = dd;
-        ecross[i] = cross;
+        ecross[i] = k == 0 ? (cross | (nv << 1)) : cross;  // edge 0 also carries the vertex count
         meta[n_circ + i] = make_int4(iv.x, iv.y, el, C + q);
     }
+    AUV_STAMP(1);
     __syncthreads();
+    AUV_STAMP(2);
 
     // ---- phase 2a: prefix sum of the interval lengths (thread-local + wave scan)
     const int chunk = (NP + nthr - 1) / nthr;
@@ -411,61 +447,100 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
     // ---- phase 2b: obstacle-level outputs.  Three independent tasks per
     // obstacle, each on a wave of its own so that no wave runs two of the long
     // fp64 chains back to back: 0 = distance (polygons: from their edges; also
-    // the deferred write-back of the advanced position), relative speed and
-    // risk; 1 = bearing; 2 = course.
+    // the deferred write-back of the advanced position), relative speed, risk
+    // and the per-env summary; 1 = bearing; 2 = course.
     {
         const int n_waves = nthr >> 6;
         const int wave = tid >> 6;
+        const int n_obst = ne * O;
+        // when an env's obstacles sit in an aligned power-of-two group of lanes
+        // of one wave, its nearest obstacle is a shuffle reduction
+        const bool lanes_per_env = O > 0 && (O & (O - 1)) == 0 && TE * O <= 64;
         for (int task = wave; task < 3; task += n_waves) {
-            for (int i = lane; i < ne * O; i += 64) {
-                const int el = i / O;
-                const int o = i - el * O;
+            for (int i0 = 0; i0 < n_obst || (task == 0 && i0 == 0); i0 += 64) {
+                const int i = i0 + lane;
+                const bool live = i < n_obst;
+                const int el = live ? i / (O > 0 ? O : 1) : 0;
+                const int o = live ? i - el * O : 0;
                 const int e = e0 + el;
-                double* ob = obst + (size_t)i * OB_COUNT;
-                const double mx = ob[OB_MX], my = ob[OB_MY], rvx = ob[OB_RVX], rvy = ob[OB_RVY];
-                const size_t eo = (size_t)e * O + o;
-                double* m = a.meta + eo * 5;
-                if (task == 0) {
-                    double dist = ob[OB_DIST];
-                    double hd = 0.0;
-                    if (o >= C) {
-                        const int q = o - C;
-                        const size_t ep = (size_t)e * P + q;
-                        if (a.is_step) {
-                            // every edge thread has read the old position before the barrier
-                            double* p = a.poly_pose + ep * 6;
-                            p[0] = p[0] + p[4] * a.dt;
-                            p[1] = p[1] + p[5] * a.dt;
+                double dist = __builtin_inf();
+                if (live) {
+                    double* ob = obst + (size_t)i * OB_COUNT;
+                    const double mx = ob[OB_MX], my = ob[OB_MY], rvx = ob[OB_RVX], rvy = ob[OB_RVY];
+                    const size_t eo = (size_t)e * O + o;
+                    double* m = a.meta + eo * 5;
+                    if (task == 0) {
+                        dist = ob[OB_DIST];
+                        double hd = 0.0;
+                        if (o >= C) {
+                            const int q = o - C;
+                            if (a.is_step) {
+                                // every edge thread has read the old position before the barrier
+                                double* pp = a.poly_pose + ((size_t)e * P + q) * 6;
+                                pp[0] = ob[OB_X];
+                                pp[1] = ob[OB_Y];
+                            }
+                            const int s0 = el * S + q * NV;
+                            const int nv = ecross[s0] >> 1;
+                            double dmin = __builtin_inf();
+                            int par = 0;
+                            for (int k = 0; k < nv; ++k) {
+                                const double dd = edist[s0 + k];
+                                dmin = dd < dmin ? dd : dmin;
+                                par ^= ecross[s0 + k] & 1;
+                            }
+                            dist = nv > 0 ? (par ? -dmin : dmin) - a.vessel_radius : __builtin_inf();
+                            ob[OB_DIST] = dist;
+                            hd = ob[OB_HEADING];
                         }
-                        const int nv = a.poly_nv[ep];
-                        double dmin = __builtin_inf();
-                        int par = 0;
-                        const int s0 = el * S + q * NV;
-                        for (int k = 0; k < nv; ++k) {
-                            const double dd = edist[s0 + k];
-                            dmin = dd < dmin ? dd : dmin;
-                            par ^= ecross[s0 + k];
-                        }
-                        dist = nv > 0 ? (par ? -dmin : dmin) - a.vessel_radius : __builtin_inf();
-                        ob[OB_DIST] = dist;
-                        hd = a.poly_heading[ep];
+                        const double vv = rvx * rvx + rvy * rvy;
+                        a.obst_dist[eo] = dist;
+                        m[0] = hd;
+                        m[1] = dist;
+                        m[2] = __builtin_sqrt(vv);
+                        a.risk[eo] = risk_index(mx, my, rvx, rvy, vv, dist, range, a.w_d, a.w_c, a.t_c);
+                    } else {
+                        const double psi = a.state[2 * (size_t)V + e];
+                        m[2 + task] = wrap_angle(atan2_det(task == 1 ? my : rvy, task == 1 ? mx : rvx) - psi);
                     }
-                    const double vv = rvx * rvx + rvy * rvy;
-                    a.obst_dist[eo] = dist;
-                    m[0] = hd;
-                    m[1] = dist;
-                    m[2] = __builtin_sqrt(vv);
-                    a.risk[eo] = risk_index(mx, my, rvx, rvy, vv, dist, range, a.w_d, a.w_c, a.t_c);
-                } else {
-                    const double psi = a.state[2 * (size_t)V + e];
-                    m[2 + task] = wrap_angle(atan2_det(task == 1 ? my : rvy, task == 1 ? mx : rvx) - psi);
+                }
+                if (task == 0 && lanes_per_env) {
+                    // (dist, id) lexicographic minimum over the env's O lanes; all 64 lanes take part
+                    double bd = dist;
+                    int bi = o;
+                    for (int d = O >> 1; d >= 1; d >>= 1) {
+                        const double od = __shfl_xor(bd, d, 64);
+                        const int oi = __shfl_xor(bi, d, 64);
+                        if (od < bd || (od == bd && oi < bi)) {
+                            bd = od;
+                            bi = oi;
+                        }
+                    }
+                    if (live && o == 0) env_summary(a, e, bd, bd < __builtin_inf() ? bi : -1);
+                }
+            }
+            if (task == 0 && !lanes_per_env) {
+                // general shape: the wave that wrote the distances walks them per env
+                for (int el = lane; el < ne; el += 64) {
+                    double bd = __builtin_inf();
+                    int bi = -1;
+                    for (int o = 0; o < O; ++o) {
+                        const double d = obst[((size_t)el * O + o) * OB_COUNT + OB_DIST];
+                        if (d < bd) {
+                            bd = d;
+                            bi = o;
+                        }
+                    }
+                    env_summary(a, e0 + el, bd, bi);
                 }
             }
         }
     }
+    AUV_STAMP(3);
     __syncthreads();
+    AUV_STAMP(4);
 
-    // ---- phase 3a: finish the prefix sum
+    // ---- phase 3: finish the prefix sum
     int base = 0;
     for (int wv = 0; wv < (tid >> 6); ++wv) base += wsum[wv];
     int run = base + incl - mine;
@@ -476,37 +551,12 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
     int total = 0;
     for (int wv = 0; wv < (nthr >> 6); ++wv) total += wsum[wv];
 
-    // ---- phase 3b: per env (highest thread ids): nearest obstacle, collision, reward, done
-    for (int el = nthr - 1 - tid; el < ne; el += nthr) {
-        const int e = e0 + el;
-        double bd = __builtin_inf();
-        int bi = -1;
-        for (int o = 0; o < O; ++o) {
-            const double d = obst[((size_t)el * O + o) * OB_COUNT + OB_DIST];
-            if (d < bd) {
-                bd = d;
-                bi = o;
-            }
-        }
-        const uint8_t coll = bd < 0.0 ? 1 : 0;
-        const uint8_t goal = a.reached_goal[e];
-        a.min_dist[e] = bd;
-        a.min_idx[e] = bi;
-        a.collision[e] = coll;
-        double rew = 0.0;
-        if (a.is_step) {
-            rew = a.envrec[(size_t)e * ER_COUNT + ER_REWARD];
-            rew = rew - (coll ? a.rw_collision : 0.0);
-            rew = rew + (goal ? a.rw_goal : 0.0);
-        }
-        a.reward[e] = rew;
-        a.done[e] = coll | goal | a.truncated[e];
-    }
-
     // ---- phase 4: LiDAR sweeps over the dense pair list, `cap` pairs per round
     // (offs[] of one thread's own primitives is all the expansion below reads
     // when there is one round, but other rounds read all of it: barrier first)
+    AUV_STAMP(5);
     __syncthreads();
+    AUV_STAMP(6);
     const int n_rounds = (total + a.cap - 1) / a.cap;
     if (n_rounds == 1) {
         // common case: the keys of sweep 0 stay in registers, sweep 1 does no arithmetic
@@ -515,7 +565,9 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
             const int cnt = meta[p].y;
             for (int k = 0; k < cnt; ++k) pairs[o + k] = ((unsigned int)p << 16) | (unsigned int)k;
         }
+        AUV_STAMP(7);
         __syncthreads();
+        AUV_STAMP(8);
         PairHit kept[kKeep];
 #pragma unroll
         for (int j = 0; j < kKeep; ++j) {
@@ -530,7 +582,9 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
             const PairHit h = pair_test(pairs[w], R, n_circ, range, meta, env, circ, seg, a.ray_dirs);
             if (h.ok) atomicMin(&best[h.slot], h.key);
         }
+        AUV_STAMP(9);
         __syncthreads();
+        AUV_STAMP(10);
 #pragma unroll
         for (int j = 0; j < kKeep; ++j)
             if (kept[j].ok && best[kept[j].slot] == kept[j].key) atomicMin(&ids[kept[j].slot], kept[j].oid);
@@ -538,7 +592,9 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
             const PairHit h = pair_test(pairs[w], R, n_circ, range, meta, env, circ, seg, a.ray_dirs);
             if (h.ok && best[h.slot] == h.key) atomicMin(&ids[h.slot], h.oid);
         }
+        AUV_STAMP(11);
         __syncthreads();
+        AUV_STAMP(12);
     } else {
         for (int pass = 0; pass < 2; ++pass) {
             for (int rd = 0; rd < n_rounds; ++rd) {
@@ -570,6 +626,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         a.hit[out] = (int)ids[f];
         a.perception[out] = (float)(1.0 - t / range);
     }
+    AUV_STAMP(13);
 }
 
 }  // namespace auv

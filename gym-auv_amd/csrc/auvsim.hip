@@ -69,7 +69,7 @@ struct auv_sim {
     int lidar_te = 1, lidar_block = 256, enc_eb = 1;
     size_t lidar_lds = 0, enc_lds = 0;
     int lidar_mode = AUV_LIDAR_RASTER;
-    int raster_te = 1, raster_cap = 2048;
+    int raster_te = 1, raster_cap = 2048, sense_block = 256;
     size_t raster_lds = 0;
     // profiling
     bool profiling = false;
@@ -136,7 +136,7 @@ hipStream_t pick(auv_sim*, void* stream) { return (hipStream_t)stream; }
 // primitive without a second round, between 1024 and 4096, a power of two.
 int pair_cap(const Dims& d, int te) {
     const long long want = (long long)te * (d.C + d.P * d.NV) * 4;
-    int cap = 1024;
+    int cap = 256;
     while (cap < 4096 && cap < want) cap <<= 1;
     return cap;
 }
@@ -259,7 +259,7 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.rw_collision = h->cfg.reward[1];
     sa.rw_goal = h->cfg.reward[2];
     const int blocks = (d.V + h->raster_te - 1) / h->raster_te;
-    hipLaunchKernelGGL(k_sense, dim3(blocks), dim3(256), h->raster_lds, st, sa);
+    hipLaunchKernelGGL(k_sense, dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
     HIP_TRY(h, hipGetLastError());
     if (ev) HIP_TRY(h, hipEventRecord(ev[3], st));
     return AUV_OK;
@@ -734,6 +734,11 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
                             h->raster_lds);
             h->lidar_mode = value;
             return AUV_OK;
+        case AUV_OPT_SENSE_BLOCK:
+            if (value != 64 && value != 128 && value != 256)
+                return fail(h, AUV_ERR_ARG, "auv_set_option: k_sense workgroup size must be 64, 128 or 256");
+            h->sense_block = value;
+            return AUV_OK;
         case AUV_OPT_RASTER_TILE:
             if (value < 0 || value > 64)
                 return fail(h, AUV_ERR_ARG, "auv_set_option: envs per workgroup must be 0 (auto) or 1..64");
@@ -771,6 +776,13 @@ int auv_profile_read(auv_handle h, double ms[3], int64_t* n_steps) {
     h->prof_steps = 0;
     return AUV_OK;
 }
+
+#ifdef AUV_PHASE_STAMPS
+// diagnostic builds only: device buffer [blocks*4*16] of i64 that k_sense stamps
+int auv_debug_set_stamps(void* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof p) == hipSuccess ? AUV_OK : AUV_ERR_DEVICE;
+}
+#endif
 
 // ---- dataset text rows (host only) ------------------------------------------
 

@@ -104,7 +104,8 @@ typedef enum auv_buffer {
  * cross-check of the rasterising default. */
 typedef enum auv_option {
     AUV_OPT_LIDAR_MODE = 0,   /* AUV_LIDAR_RASTER (default) | AUV_LIDAR_ALL_PAIRS */
-    AUV_OPT_RASTER_TILE = 1   /* envs per workgroup of the rasterising kernel; 0 = auto */
+    AUV_OPT_RASTER_TILE = 1,  /* envs per workgroup of the rasterising kernel; 0 = auto */
+    AUV_OPT_SENSE_BLOCK = 2   /* threads per k_sense workgroup: 64, 128 or 256 */
 } auv_option;
 #define AUV_LIDAR_RASTER 0
 #define AUV_LIDAR_ALL_PAIRS 1

@@ -1,0 +1,29 @@
+import os, sys, ctypes as C
+sys.path.insert(0, '.')
+os.environ["AUVSIM_LIB"] = os.path.abspath("scratch/libauvsim_stamps.so")
+import torch, numpy as np
+from gym_auv_amd import scenarios, _lib
+from gym_auv_amd.sim import AuvSim
+V = 65536
+cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=V)
+sim = AuvSim(cfg); sim.set_scene(scene)
+st = torch.cuda.current_stream()
+sim.reset(scene["init_state"], stream=st)
+acts = torch.from_numpy(scenarios.random_actions(V, 8, seed=100)).cuda()
+for k in range(100): sim.step_device(acts[k % 8].data_ptr(), stream=st)
+nblk = V // 4
+stamps = torch.zeros(nblk * 4 * 16, dtype=torch.int64, device="cuda")
+lib = _lib.load()
+lib.auv_debug_set_stamps.argtypes = [C.c_void_p]
+assert lib.auv_debug_set_stamps(C.c_void_p(stamps.data_ptr())) == 0
+sim.step_device(acts[0].data_ptr(), stream=st)
+torch.cuda.synchronize()
+s = stamps.cpu().numpy().reshape(nblk, 4, 16)[:, :, :14].astype(np.float64)
+d = np.diff(s, axis=2)          # [blk, wave, 13]
+names = ["P1 stage", "bar1", "P2 scan+obst", "bar2", "P3 offs+env", "bar3", "expand", "bar4", "sweep0", "bar5", "sweep1", "bar6", "output"]
+tot = (s[:, :, 13] - s[:, :, 0])
+print("wave lifetime mean cycles", tot.mean(), "(100 MHz ticks? memtime = shader clock)")
+for w in range(4):
+    print("wave", w, " ".join(f"{n}:{d[:, w, i].mean():7.0f}" for i, n in enumerate(names)))
+print("all  ", " ".join(f"{n}:{d[:, :, i].mean():7.0f}" for i, n in enumerate(names)))
+print("block span (first stamp to last stamp over waves)", (s[:, :, 13].max(1) - s[:, :, 0].min(1)).mean())
