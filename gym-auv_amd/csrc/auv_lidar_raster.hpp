@@ -14,8 +14,8 @@
 // Exactness: the interval and range culls only decide which pairs are tried;
 // every accept/reject and every reported number comes from the same exact
 // test as the all-pairs kernel.  The culls use fp32 angles with an outward
-// margin (0.02 ray spacings, >= 1e-4 rad for any scan this library accepts)
-// that is orders of magnitude above both the fp32 error (~1e-6 rad) and the
+// margin (0.02 ray spacings and at least 1e-4 rad) that is orders of
+// magnitude above both the fp32 error (~2e-6 rad) and the
 // deviation between the fp64 predicates and exact geometry (<= ~1e-8 rad), so
 // no pair that the exact test would accept is ever skipped.
 #pragma once
@@ -23,8 +23,34 @@
 
 namespace auv {
 
-constexpr float kIvMargin = 0.02f;      // ray spacings added on each side
-constexpr float kRangeSlack = 1.0001f;  // relative slack of the range cull
+constexpr float kIvMargin = 0.02f;        // ray spacings added on each side, and at least ...
+constexpr float kIvMarginRad = 1.0e-4f;   // ... this many radians (matters for very dense scans)
+constexpr float kRangeSlack = 1.0001f;    // relative slack of the range cull
+
+// atan2 for the candidate intervals only: odd minimax polynomial of the octant
+// ratio, |error| < 2e-6 rad (fp32 evaluation included), no special cases: the
+// callers never pass a vector shorter than 1e-3.  Far inside kIvMarginRad.
+__device__ __forceinline__ float fast_atan2f(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
+    const float z = lo * __builtin_amdgcn_rcpf(hi);
+    const float z2 = z * z;
+    float p = -0.011719128f;
+    p = 0.052647337f + z2 * p;
+    p = -0.116426475f + z2 * p;
+    p = 0.193540379f + z2 * p;
+    p = -0.332622826f + z2 * p;
+    p = 0.999977231f + z2 * p;
+    float a = z * p;
+    a = ay > ax ? 1.57079633f - a : a;
+    a = x < 0.0f ? 3.14159265f - a : a;
+    return y < 0.0f ? -a : a;
+}
+
+// i / d for 0 <= i < 2^20 and 1 <= d < 2^16 through one fp32 multiply
+// (inv_d = 1.0f / d): (i + 0.5) / d is at least 0.5/d away from an integer,
+// far more than the rounding error of the product at these magnitudes.
+__device__ __forceinline__ int fast_div(int i, float inv_d) { return (int)(((float)i + 0.5f) * inv_d); }
 
 // fractional scan index of a world bearing: ray i sits at x = i, x in [-1, R-1)
 __device__ __forceinline__ float scan_index(float bearing, float psi, float inv_delta) {
@@ -34,9 +60,9 @@ __device__ __forceinline__ float scan_index(float bearing, float psi, float inv_
     return (w + pi) * inv_delta - 1.0f;
 }
 
-__device__ __forceinline__ int2 make_interval(float lo, float hi, int R) {
-    const int ilo = (int)floorf(lo - kIvMargin);
-    const int ihi = (int)ceilf(hi + kIvMargin);
+__device__ __forceinline__ int2 make_interval(float lo, float hi, int R, float margin) {
+    const int ilo = (int)floorf(lo - margin);
+    const int ihi = (int)ceilf(hi + margin);
     int cnt = ihi - ilo + 1;
     int first = ilo % R;
     if (first < 0) first += R;

@@ -249,7 +249,8 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
     const int V = a.d.V, R = a.d.R, C = a.d.C, P = a.d.P, NV = a.d.NV, O = a.d.O;
     const int S = P * NV;
     const int TE = a.TE;
-    const SenseLayout L = sense_layout(TE, R, C, P, NV, a.cap);
+    const int cap = a.cap;
+    const SenseLayout L = sense_layout(TE, R, C, P, NV, cap);
     double* env = reinterpret_cast<double*>(lds_raw + L.env);
     double* circ = reinterpret_cast<double*>(lds_raw + L.circ);
     double* seg = reinterpret_cast<double*>(lds_raw + L.seg);
@@ -261,21 +262,30 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
     unsigned int* ids = reinterpret_cast<unsigned int*>(lds_raw + L.ids);
     unsigned int* pairs = reinterpret_cast<unsigned int*>(lds_raw + L.pairs);
     int* ecross = reinterpret_cast<int*>(lds_raw + L.ecross);
-    int* wsum = reinterpret_cast<int*>(lds_raw + L.wsum);
+    int* wsum = reinterpret_cast<int*>(lds_raw + L.wsum);  // [0..3] wave sums of the fallback scan, [6],[7] pair counters
     const int e0 = blockIdx.x * TE;
     const int ne = min(TE, V - e0);
     const int n_circ = ne * C;
     const int NP = n_circ + ne * S;
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
+    const int lane = tid & 63;
     const double range = a.sensor_range;
     const float frange = (float)range * kRangeSlack;
     const float inv_delta = (float)R * (1.0f / 6.2831853f);
     const float half_scan = 0.5f * (float)R;
+    const float margin = fmaxf(kIvMargin, kIvMarginRad * inv_delta);
+    const float inv_C = 1.0f / (float)(C > 0 ? C : 1), inv_S = 1.0f / (float)(S > 0 ? S : 1);
+    const float inv_NV = 1.0f / (float)NV, inv_O = 1.0f / (float)(O > 0 ? O : 1);
 
     AUV_STAMP(0);
-    // ---- phase 1: per-ray accumulators, heading sin/cos, primitives.  Nothing
-    // here reads LDS written by another thread, so no barrier is needed before.
+    // ---- phase 0: accumulators.  The pair list is filled from both ends:
+    // circle pairs grow up from slot 0 (count in wsum[6]), edge pairs grow down
+    // from slot cap (count in wsum[7]), so a wave of the sweep sees one kind.
+    if (tid == 0) {
+        wsum[6] = 0;
+        wsum[7] = 0;
+    }
     for (int el = tid; el < ne; el += nthr) {
         const double* er = a.envrec + (size_t)(e0 + el) * ER_COUNT;
         env[el * 2] = er[ER_COS];
@@ -286,10 +296,13 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         best[f] = range_bits;
         ids[f] = 0xffffffffu;
     }
-    // circles go to the highest thread ids, so that on small tiles they do not
-    // share a wave with the first edges
+    __syncthreads();
+    AUV_STAMP(1);
+
+    // ---- phase 1: primitives.  Circles go to the highest thread ids, so that
+    // on small tiles they do not share a wave with the first edges.
     for (int i = nthr - 1 - tid; i < n_circ; i += nthr) {
-        const int el = i / C;
+        const int el = fast_div(i, inv_C);
         const int j = i - el * C;
         const int e = e0 + el;
         double* c = a.circles + ((size_t)e0 * C + i) * 5;
@@ -329,21 +342,31 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         } else if (sqrtf(fmm) - fr > frange) {
             // wholly beyond sensor range
         } else {
-            const float xc = scan_index(atan2f(fmy, fmx), (float)psi, inv_delta);
-            const float hw = atan2f(fr, sqrtf(fmm - fr * fr)) * inv_delta;
-            iv = make_interval(xc - hw, xc + hw, R);
+            const float xc = scan_index(fast_atan2f(fmy, fmx), (float)psi, inv_delta);
+            const float hw = fast_atan2f(fr, sqrtf(fmm - fr * fr)) * inv_delta;
+            iv = make_interval(xc - hw, xc + hw, R, margin);
         }
         meta[i] = make_int4(iv.x, iv.y, el, j);
+        if (iv.y > 0) {
+            const int base = atomicAdd(&wsum[6], iv.y);
+            const int room = min(iv.y, cap - base);  // writes stay inside the list even when it overflows
+            for (int k = 0; k < room; ++k) pairs[base + k] = ((unsigned int)i << 16) | (unsigned int)k;
+        }
     }
     for (int i = tid; i < ne * S; i += nthr) {
-        const int el = i / S;
+        const int el = fast_div(i, inv_S);
         const int s = i - el * S;
-        const int q = s / NV;
+        const int q = fast_div(s, inv_NV);
         const int k = s - q * NV;
         const int e = e0 + el;
         const size_t ep = (size_t)e * P + q;
         const int nv = a.poly_nv[ep];
         const double* p = a.poly_pose + ep * 6;
+        // every vertex slot exists in memory, so the loads need not wait for nv
+        const double* vb = a.poly_verts + ep * NV * 2;
+        const int k1c = (k + 1 < NV) ? k + 1 : 0;
+        const double vkx = vb[2 * k], vky = vb[2 * k + 1];
+        const double v1x = vb[2 * k1c], v1y = vb[2 * k1c + 1], v0x = vb[0], v0y = vb[1];
         double X = p[0], Y = p[1];
         const double ch = p[2], sh = p[3], pvx = p[4], pvy = p[5];
         if (a.is_step) {
@@ -368,12 +391,12 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         int cross = 0;
         int2 iv = make_int2(0, 0);
         if (k < nv) {
-            const double* vb = a.poly_verts + ep * NV * 2;
-            const int k1 = (k + 1 < nv) ? k + 1 : 0;
-            const double Ax = X + (ch * vb[2 * k] - sh * vb[2 * k + 1]);
-            const double Ay = Y + (sh * vb[2 * k] + ch * vb[2 * k + 1]);
-            const double Bx = X + (ch * vb[2 * k1] - sh * vb[2 * k1 + 1]);
-            const double By = Y + (sh * vb[2 * k1] + ch * vb[2 * k1 + 1]);
+            const bool wrap = k + 1 >= nv;  // the last edge closes on vertex 0
+            const double bx = wrap ? v0x : v1x, by_ = wrap ? v0y : v1y;
+            const double Ax = X + (ch * vkx - sh * vky);
+            const double Ay = Y + (sh * vkx + ch * vky);
+            const double Bx = X + (ch * bx - sh * by_);
+            const double By = Y + (sh * bx + ch * by_);
             ax = Ax - px;
             ay = Ay - py;
             const double by = By - py;
@@ -404,8 +427,8 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
             } else if (aa < 1e-6f || bb < 1e-6f || dmin < 1e-3f) {
                 iv.y = R;  // an endpoint (or the edge) is on top of the vessel: bearings are meaningless
             } else {
-                const float xa = scan_index(atan2f(fay, fax), (float)psi, inv_delta);
-                const float xb = scan_index(atan2f(fby, fbx), (float)psi, inv_delta);
+                const float xa = scan_index(fast_atan2f(fay, fax), (float)psi, inv_delta);
+                const float xb = scan_index(fast_atan2f(fby, fbx), (float)psi, inv_delta);
                 float d = xb - xa;
                 d = d > half_scan ? d - (float)R : d;
                 d = d < -half_scan ? d + (float)R : d;
@@ -413,7 +436,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
                     iv.y = R;  // subtends ~180 deg: the short way round is ambiguous
                 } else {
                     const float lo = d >= 0.0f ? xa : xa + d;
-                    iv = make_interval(lo, lo + fabsf(d), R);
+                    iv = make_interval(lo, lo + fabsf(d), R, margin);
                 }
             }
         }
@@ -426,25 +449,22 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         edist[i] = dd;
         ecross[i] = k == 0 ? (cross | (nv << 1)) : cross;  // edge 0 also carries the vertex count
         meta[n_circ + i] = make_int4(iv.x, iv.y, el, C + q);
+        if (iv.y > 0) {
+            const int used = atomicAdd(&wsum[7], iv.y);
+            const int top = cap - used;  // exclusive upper slot of this primitive's run
+            const int room = min(iv.y, top);
+            for (int kk = 0; kk < room; ++kk)
+                pairs[top - 1 - kk] = ((unsigned int)(n_circ + i) << 16) | (unsigned int)kk;
+        }
     }
-    AUV_STAMP(1);
-    __syncthreads();
     AUV_STAMP(2);
+    __syncthreads();
+    AUV_STAMP(3);
+    const int n_cp = wsum[6], n_ep = wsum[7];
+    const int total = n_cp + n_ep;
+    const bool fits = total <= cap;
 
-    // ---- phase 2a: prefix sum of the interval lengths (thread-local + wave scan)
-    const int chunk = (NP + nthr - 1) / nthr;
-    const int p_lo = min(tid * chunk, NP), p_hi = min(p_lo + chunk, NP);
-    int mine = 0;
-    for (int p = p_lo; p < p_hi; ++p) mine += meta[p].y;
-    int incl = mine;
-    const int lane = tid & 63;
-    for (int d = 1; d < 64; d <<= 1) {
-        const int up = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += up;
-    }
-    if (lane == 63) wsum[tid >> 6] = incl;
-
-    // ---- phase 2b: obstacle-level outputs.  Three independent tasks per
+    // ---- phase 2: obstacle-level outputs.  Three independent tasks per
     // obstacle, each on a wave of its own so that no wave runs two of the long
     // fp64 chains back to back: 0 = distance (polygons: from their edges; also
     // the deferred write-back of the advanced position), relative speed, risk
@@ -460,7 +480,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
             for (int i0 = 0; i0 < n_obst || (task == 0 && i0 == 0); i0 += 64) {
                 const int i = i0 + lane;
                 const bool live = i < n_obst;
-                const int el = live ? i / (O > 0 ? O : 1) : 0;
+                const int el = live ? fast_div(i, inv_O) : 0;
                 const int o = live ? i - el * O : 0;
                 const int e = e0 + el;
                 double dist = __builtin_inf();
@@ -536,73 +556,72 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
             }
         }
     }
-    AUV_STAMP(3);
-    __syncthreads();
     AUV_STAMP(4);
 
-    // ---- phase 3: finish the prefix sum
-    int base = 0;
-    for (int wv = 0; wv < (tid >> 6); ++wv) base += wsum[wv];
-    int run = base + incl - mine;
-    for (int p = p_lo; p < p_hi; ++p) {
-        offs[p] = run;
-        run += meta[p].y;
-    }
-    int total = 0;
-    for (int wv = 0; wv < (nthr >> 6); ++wv) total += wsum[wv];
-
-    // ---- phase 4: LiDAR sweeps over the dense pair list, `cap` pairs per round
-    // (offs[] of one thread's own primitives is all the expansion below reads
-    // when there is one round, but other rounds read all of it: barrier first)
-    AUV_STAMP(5);
-    __syncthreads();
-    AUV_STAMP(6);
-    const int n_rounds = (total + a.cap - 1) / a.cap;
-    if (n_rounds == 1) {
-        // common case: the keys of sweep 0 stay in registers, sweep 1 does no arithmetic
-        for (int p = tid; p < NP; p += nthr) {
-            const int o = offs[p];
-            const int cnt = meta[p].y;
-            for (int k = 0; k < cnt; ++k) pairs[o + k] = ((unsigned int)p << 16) | (unsigned int)k;
-        }
-        AUV_STAMP(7);
-        __syncthreads();
-        AUV_STAMP(8);
+    // ---- phase 3: LiDAR sweeps (same barrier interval as phase 2: they share nothing)
+    if (fits) {
+        // the whole pair list is in LDS: the keys of sweep 0 stay in registers,
+        // sweep 1 does no arithmetic.  Pair w: circles first, then edges.
         PairHit kept[kKeep];
 #pragma unroll
         for (int j = 0; j < kKeep; ++j) {
             kept[j].ok = false;
             const int w = tid + j * nthr;
             if (w < total) {
-                kept[j] = pair_test(pairs[w], R, n_circ, range, meta, env, circ, seg, a.ray_dirs);
+                kept[j] = pair_test(pairs[w < n_cp ? w : cap - n_ep + (w - n_cp)], R, n_circ, range, meta, env, circ,
+                                    seg, a.ray_dirs);
                 if (kept[j].ok) atomicMin(&best[kept[j].slot], kept[j].key);
             }
         }
         for (int w = tid + kKeep * nthr; w < total; w += nthr) {
-            const PairHit h = pair_test(pairs[w], R, n_circ, range, meta, env, circ, seg, a.ray_dirs);
+            const PairHit h = pair_test(pairs[w < n_cp ? w : cap - n_ep + (w - n_cp)], R, n_circ, range, meta, env,
+                                        circ, seg, a.ray_dirs);
             if (h.ok) atomicMin(&best[h.slot], h.key);
         }
-        AUV_STAMP(9);
+        AUV_STAMP(5);
         __syncthreads();
-        AUV_STAMP(10);
+        AUV_STAMP(6);
 #pragma unroll
         for (int j = 0; j < kKeep; ++j)
             if (kept[j].ok && best[kept[j].slot] == kept[j].key) atomicMin(&ids[kept[j].slot], kept[j].oid);
         for (int w = tid + kKeep * nthr; w < total; w += nthr) {
-            const PairHit h = pair_test(pairs[w], R, n_circ, range, meta, env, circ, seg, a.ray_dirs);
+            const PairHit h = pair_test(pairs[w < n_cp ? w : cap - n_ep + (w - n_cp)], R, n_circ, range, meta, env,
+                                        circ, seg, a.ray_dirs);
             if (h.ok && best[h.slot] == h.key) atomicMin(&ids[h.slot], h.oid);
         }
-        AUV_STAMP(11);
+        AUV_STAMP(7);
         __syncthreads();
-        AUV_STAMP(12);
+        AUV_STAMP(8);
     } else {
+        // more pairs than slots (dense scenes, vessel inside obstacles): rounds of
+        // `cap` pairs, each re-expanded from a prefix sum of the interval lengths
+        const int chunk = (NP + nthr - 1) / nthr;
+        const int p_lo = min(tid * chunk, NP), p_hi = min(p_lo + chunk, NP);
+        int mine = 0;
+        for (int p = p_lo; p < p_hi; ++p) mine += meta[p].y;
+        int incl = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wsum[tid >> 6] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int wv = 0; wv < (tid >> 6); ++wv) base += wsum[wv];
+        int run = base + incl - mine;
+        for (int p = p_lo; p < p_hi; ++p) {
+            offs[p] = run;
+            run += meta[p].y;
+        }
+        __syncthreads();
+        const int n_rounds = (total + cap - 1) / cap;
         for (int pass = 0; pass < 2; ++pass) {
             for (int rd = 0; rd < n_rounds; ++rd) {
-                const int w0 = rd * a.cap;
-                const int n_pairs = min(a.cap, total - w0);
+                const int w0 = rd * cap;
+                const int n_pairs = min(cap, total - w0);
                 for (int p = tid; p < NP; p += nthr) {
                     const int o = offs[p];
-                    const int lo = max(o, w0), hi = min(o + meta[p].y, w0 + a.cap);
+                    const int lo = max(o, w0), hi = min(o + meta[p].y, w0 + cap);
                     for (int w = lo; w < hi; ++w) pairs[w - w0] = ((unsigned int)p << 16) | (unsigned int)(w - o);
                 }
                 __syncthreads();
@@ -618,7 +637,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         }
     }
 
-    // ---- phase 5: 16 B per ray, coalesced
+    // ---- phase 4: 16 B per ray, coalesced
     for (int f = tid; f < ne * R; f += nthr) {
         const double t = __longlong_as_double((long long)best[f]);
         const size_t out = (size_t)e0 * R + f;
@@ -626,7 +645,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         a.hit[out] = (int)ids[f];
         a.perception[out] = (float)(1.0 - t / range);
     }
-    AUV_STAMP(13);
+    AUV_STAMP(9);
 }
 
 }  // namespace auv
