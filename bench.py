@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--block", type=int, default=0, help="threads per k_sense workgroup (64/128/256), 0 = default")
     ap.add_argument("--cnn", default="shallow", choices=["none", "shallow", "deep2", "deep"],
                     help="LiDAR CNN fed zero-copy with every step's scans (features head)")
+    ap.add_argument("--cnn-mode", default="attached", choices=["attached", "separate"],
+                    help="attached: evaluated inside the sensing kernel; separate: its own launch per step")
     ap.add_argument("--gather-scans", action="store_true",
                     help="also gather the final scans of every rank on rank 0 once per rollout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -125,6 +127,7 @@ def main():
 
     # the consumer of the scans: the reference's shipped weights (fixture made from its own files)
     net = feats = per_t = None
+    cnn_dim = 0   # outputs per scan of a network attached to the sensing kernel
     if args.cnn != "none" and R == 180:
         import numpy as np
 
@@ -134,8 +137,14 @@ def main():
         pre = f"w_{args.cnn}/"
         net = cnn.LidarCNN(args.cnn, {k[len(pre):]: gold[k] for k in gold.files if k.startswith(pre)},
                            device=local_rank)
-        per_t = sim.tensor("perception")
-        feats = torch.empty((V, net.out_dim("features")), dtype=torch.float32, device=dev)
+        if args.cnn_mode == "attached":
+            sim.attach_cnn(net, "features")
+            cnn_dim = net.out_dim("features")
+            net.close()
+            net = None
+        else:
+            per_t = sim.tensor("perception")
+            feats = torch.empty((V, net.out_dim("features")), dtype=torch.float32, device=dev)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -222,7 +231,9 @@ def main():
             "config": {"workload": args.workload, "vessels_per_gpu": V, "rays": R, "circles": C,
                        "polygons": P, "edges_per_polygon": NV, "sensor_range_m": cfg["sensor_range"],
                        "dt_s": cfg["dt"], "lidar": "rasterising, fused k_sense" if fused else "all pairs, 3 kernels",
-                       "cnn": (f"{args.cnn} (features head) on every step's scans, zero-copy" if net is not None
+                       "cnn": (f"{args.cnn} (features head) on every step's scans, separate launch, zero-copy"
+                               if net is not None else
+                               f"{args.cnn} (features head) on every step's scans, inside k_sense" if cnn_dim
                                else "none"),
                        "sharding": f"envs x{world}, no data-path collective"},
             "kernel_ms": ({"k_vessel": vessel_s * 1e3, "k_sense": sense_s * 1e3} if fused else
@@ -236,7 +247,7 @@ def main():
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cb / cnn_ms / 1e6 / HBM_PEAK_GBS,
                                    "traffic": None, "avg_launch_ms": cnn_ms}
         if fused:
-            nbytes = float(sense_bytes_per_env(R, C, P, NV)) * V
+            nbytes = float(sense_bytes_per_env(R, C, P, NV) + 4 * cnn_dim) * V
             gbs = nbytes / sense_s / 1e9
             out["roofline"] = {
                 "kernel": "k_sense", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -22,7 +22,7 @@ F64, F32, I32, U8, I64 = 0, 1, 2, 3, 4
 (BUF_STATE, BUF_ACTION, BUF_RANGES, BUF_HIT, BUF_PERCEPTION, BUF_NAVIGATION,
  BUF_OBST_DIST, BUF_RISK, BUF_META, BUF_OWN, BUF_COLLISION, BUF_REACHED_GOAL,
  BUF_TRUNCATED, BUF_DONE, BUF_MIN_DIST, BUF_MIN_IDX, BUF_ALONG, BUF_T_STEP,
- BUF_CIRCLES, BUF_POLY_POSE, BUF_REWARD, BUF_COUNT) = range(22)
+ BUF_CIRCLES, BUF_POLY_POSE, BUF_REWARD, BUF_CNN_OUT, BUF_COUNT) = range(23)
 
 BUFFER_NAMES = {
     "state": BUF_STATE, "action": BUF_ACTION, "ranges": BUF_RANGES, "hit": BUF_HIT,
@@ -31,7 +31,7 @@ BUFFER_NAMES = {
     "reached_goal": BUF_REACHED_GOAL, "truncated": BUF_TRUNCATED, "done": BUF_DONE,
     "min_dist": BUF_MIN_DIST, "min_idx": BUF_MIN_IDX, "along": BUF_ALONG,
     "t_step": BUF_T_STEP, "circles": BUF_CIRCLES, "poly_pose": BUF_POLY_POSE,
-    "reward": BUF_REWARD,
+    "reward": BUF_REWARD, "cnn_out": BUF_CNN_OUT,
 }
 
 # auv_option
@@ -49,7 +49,7 @@ EXPORTS = (
     "auv_get_buffer", "auv_read_buffer", "auv_dlpack", "auv_sync", "auv_set_option",
     "auv_profile_enable", "auv_cnn_n_weights", "auv_cnn_out_dim", "auv_cnn_create", "auv_cnn_destroy",
     "auv_cnn_forward", "auv_cnn_last_error", "auv_format_rows",
-    "auv_profile_read",
+    "auv_profile_read", "auv_attach_cnn",
 )
 
 
@@ -142,5 +142,7 @@ def load():
     lib.auv_cnn_forward.argtypes = [vp, vp, i64, i32, vp, vp]
     lib.auv_cnn_last_error.restype = C.c_char_p
     lib.auv_cnn_last_error.argtypes = [vp]
+    lib.auv_attach_cnn.restype = C.c_int
+    lib.auv_attach_cnn.argtypes = [vp, vp, i32]
     _lib = lib
     return lib

@@ -41,10 +41,10 @@ struct CnnArgs {
 // optionally followed by MaxPool1d(2, 2, ceil_mode=True) fused into the store
 template <bool RELU, bool POOL>
 __device__ __forceinline__ int conv_layer(const float* in, float* out, const float* w, const float* b, int Cin,
-                                          int Cout, int L, int K, int stride, int pad, int lane) {
+                                          int Cout, int L, int K, int stride, int pad, int lane, int n_lanes) {
     const int Lc = (L + 2 * pad - K) / stride + 1;
     const int Lo = POOL ? (Lc + 1) / 2 : Lc;
-    for (int idx = lane; idx < Cout * Lo; idx += kCnnLanes) {
+    for (int idx = lane; idx < Cout * Lo; idx += n_lanes) {
         const int co = idx / Lo;
         const int lo = idx - co * Lo;
         float best = 0.f;
@@ -57,6 +57,7 @@ __device__ __forceinline__ int conv_layer(const float* in, float* out, const flo
                 const float* xr = in + ci * L;
                 int p = pos * stride - pad;
                 p = p < 0 ? p + L : p;
+#pragma unroll 9
                 for (int k = 0; k < K; ++k) {
                     acc += wr[k] * xr[p];
                     p = (p + 1 == L) ? 0 : p + 1;
@@ -72,9 +73,10 @@ __device__ __forceinline__ int conv_layer(const float* in, float* out, const flo
 
 template <bool RELU>
 __device__ __forceinline__ void linear_layer(const float* in, float* out, const float* w, const float* b, int n_in,
-                                             int n_out, int lane) {
-    for (int o = lane; o < n_out; o += kCnnLanes) {
+                                             int n_out, int lane, int n_lanes) {
+    for (int o = lane; o < n_out; o += n_lanes) {
         float acc = 0.f;
+#pragma unroll 4
         for (int i = 0; i < n_in; ++i) acc += in[i] * w[(size_t)o * n_in + i];
         acc += b[o];
         if (RELU) acc = acc > 0.f ? acc : 0.f;
@@ -82,8 +84,82 @@ __device__ __forceinline__ void linear_layer(const float* in, float* out, const 
     }
 }
 
-// the 16 lanes of a scan live in one wave: a wave-level LDS fence is enough
+// the lanes of a scan live in one wave: a wave-level LDS fence is enough
 __device__ __forceinline__ void scan_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// LDS floats per activation buffer of one scan (two buffers are needed)
+__host__ __device__ inline int cnn_buf_floats(int kind) { return kind == CNN_DEEP ? kCnnBuf : 40; }
+// the two small networks can run inside the sensing kernel, weights staged in LDS
+__host__ __device__ inline bool cnn_fits_sense_kernel(int kind) { return kind == CNN_SHALLOW || kind == CNN_2DEEP; }
+
+// Forward pass of one scan by `nl` lanes of one wave (lane = 0..nl-1): x = the
+// 180 closeness values in LDS, p and q = two activation buffers of
+// cnn_buf_floats(kind) floats in LDS, out = the scan's row of the result in
+// global memory.  Every output element is accumulated by one lane in a fixed
+// order, so the result does not depend on nl.  WITH_DEEP = false leaves the
+// largest network out of the instantiation (kind must not be CNN_DEEP then).
+template <bool WITH_DEEP>
+__device__ __forceinline__ void cnn_forward_scan(const float* x, float* p, float* q, const float* w, float* out,
+                                                 int kind, int head, int lane, int nl) {
+    const float* res = p;
+    int n_res = 0;
+    if (kind == CNN_SHALLOW) {
+        // w: conv.weight[45] conv.bias[1] linear.weight[12] linear.bias[1]
+        if (head == HEAD_FEATURES) {
+            conv_layer<false, false>(x, p, w, w + 45, 1, 1, kCnnLen, 45, 15, 15, lane, nl);
+            res = p;
+            n_res = 12;
+        } else {
+            conv_layer<true, false>(x, p, w, w + 45, 1, 1, kCnnLen, 45, 15, 15, lane, nl);
+            scan_sync();
+            linear_layer<true>(p, q, w + 46, w + 58, 12, 1, lane, nl);
+            res = q;
+            n_res = 1;
+        }
+    } else if (!WITH_DEEP || kind == CNN_2DEEP) {
+        // w: c1.w[3*45] c1.b[3] c2.w[2*3*3] c2.b[2] c3.w[1*2*3] c3.b[1] lin.w[12] lin.b[1]
+        conv_layer<true, false>(x, p, w, w + 135, 1, 3, kCnnLen, 45, 15, 15, lane, nl);
+        scan_sync();
+        conv_layer<true, false>(p, q, w + 138, w + 156, 3, 2, 12, 3, 1, 1, lane, nl);
+        scan_sync();
+        conv_layer<false, false>(q, p, w + 158, w + 164, 2, 1, 12, 3, 1, 1, lane, nl);
+        res = p;
+        n_res = 12;
+        if (head == HEAD_RISK) {
+            scan_sync();
+            linear_layer<true>(p, q, w + 165, w + 177, 12, 1, lane, nl);
+            res = q;
+            n_res = 1;
+        }
+    } else if constexpr (WITH_DEEP) {
+        // w: c1.w[2*1*9] b[2] c2.w[4*2*9] b[4] c3.w[4*4*9] b[4] c4.w[6*4*9] b[6]
+        //    l1.w[40*72] b[40] l2.w[8*40] b[8] l3.w[8] b[1]
+        int L = conv_layer<true, true>(x, p, w, w + 18, 1, 2, kCnnLen, 9, 1, 4, lane, nl);       // 2 x 90
+        scan_sync();
+        L = conv_layer<true, true>(p, q, w + 20, w + 92, 2, 4, L, 9, 1, 4, lane, nl);            // 4 x 45
+        scan_sync();
+        L = conv_layer<true, true>(q, p, w + 96, w + 240, 4, 4, L, 9, 1, 4, lane, nl);           // 4 x 23
+        scan_sync();
+        L = conv_layer<true, true>(p, q, w + 244, w + 460, 4, 6, L, 9, 1, 4, lane, nl);          // 6 x 12
+        scan_sync();
+        linear_layer<true>(q, p, w + 466, w + 3346, 72, 40, lane, nl);
+        scan_sync();
+        linear_layer<false>(p, q, w + 3386, w + 3706, 40, 8, lane, nl);
+        res = q;
+        n_res = 8;
+        if (head == HEAD_RISK) {
+            scan_sync();
+            // ReLU on the 8 features, then Linear(8 -> 1) + ReLU
+            if (lane < 8) p[lane] = q[lane] > 0.f ? q[lane] : 0.f;
+            scan_sync();
+            linear_layer<true>(p, q + 8, w + 3714, w + 3722, 8, 1, lane, nl);
+            res = q + 8;
+            n_res = 1;
+        }
+    }
+    scan_sync();
+    for (int i = lane; i < n_res; i += nl) out[i] = res[i];
+}
 
 __global__ __launch_bounds__(256) void k_cnn(CnnArgs a) {
     __shared__ float lds[kCnnScans][3][kCnnBuf];
@@ -99,69 +175,8 @@ __global__ __launch_bounds__(256) void k_cnn(CnnArgs a) {
     const int s = tid / kCnnLanes;
     const int lane = tid - s * kCnnLanes;
     if (s >= ns) return;
-    float* x = lds[s][0];
-    float* p = lds[s][1];
-    float* q = lds[s][2];
-    const float* w = a.w;
-    float* out = a.out + (s0 + s) * cnn_out_dim(a.kind, a.head);
-    const float* res;
-    int n_res;
-    if (a.kind == CNN_SHALLOW) {
-        // w: conv.weight[45] conv.bias[1] linear.weight[12] linear.bias[1]
-        if (a.head == HEAD_FEATURES) {
-            conv_layer<false, false>(x, p, w, w + 45, 1, 1, kCnnLen, 45, 15, 15, lane);
-            res = p;
-            n_res = 12;
-        } else {
-            conv_layer<true, false>(x, p, w, w + 45, 1, 1, kCnnLen, 45, 15, 15, lane);
-            scan_sync();
-            linear_layer<true>(p, q, w + 46, w + 58, 12, 1, lane);
-            res = q;
-            n_res = 1;
-        }
-    } else if (a.kind == CNN_2DEEP) {
-        // w: c1.w[3*45] c1.b[3] c2.w[2*3*3] c2.b[2] c3.w[1*2*3] c3.b[1] lin.w[12] lin.b[1]
-        conv_layer<true, false>(x, p, w, w + 135, 1, 3, kCnnLen, 45, 15, 15, lane);
-        scan_sync();
-        conv_layer<true, false>(p, q, w + 138, w + 156, 3, 2, 12, 3, 1, 1, lane);
-        scan_sync();
-        conv_layer<false, false>(q, p, w + 158, w + 164, 2, 1, 12, 3, 1, 1, lane);
-        res = p;
-        n_res = 12;
-        if (a.head == HEAD_RISK) {
-            scan_sync();
-            linear_layer<true>(p, q, w + 165, w + 177, 12, 1, lane);
-            res = q;
-            n_res = 1;
-        }
-    } else {
-        // w: c1.w[2*1*9] b[2] c2.w[4*2*9] b[4] c3.w[4*4*9] b[4] c4.w[6*4*9] b[6]
-        //    l1.w[40*72] b[40] l2.w[8*40] b[8] l3.w[8] b[1]
-        int L = conv_layer<true, true>(x, p, w, w + 18, 1, 2, kCnnLen, 9, 1, 4, lane);       // 2 x 90
-        scan_sync();
-        L = conv_layer<true, true>(p, q, w + 20, w + 92, 2, 4, L, 9, 1, 4, lane);            // 4 x 45
-        scan_sync();
-        L = conv_layer<true, true>(q, p, w + 96, w + 240, 4, 4, L, 9, 1, 4, lane);           // 4 x 23
-        scan_sync();
-        L = conv_layer<true, true>(p, q, w + 244, w + 460, 4, 6, L, 9, 1, 4, lane);          // 6 x 12
-        scan_sync();
-        linear_layer<true>(q, p, w + 466, w + 3346, 72, 40, lane);
-        scan_sync();
-        linear_layer<false>(p, q, w + 3386, w + 3706, 40, 8, lane);
-        res = q;
-        n_res = 8;
-        if (a.head == HEAD_RISK) {
-            scan_sync();
-            // ReLU on the 8 features, then Linear(8 -> 1) + ReLU
-            if (lane < 8) p[lane] = q[lane] > 0.f ? q[lane] : 0.f;
-            scan_sync();
-            linear_layer<true>(p, q + 8, w + 3714, w + 3722, 8, 1, lane);
-            res = q + 8;
-            n_res = 1;
-        }
-    }
-    scan_sync();
-    for (int i = lane; i < n_res; i += kCnnLanes) out[i] = res[i];
+    cnn_forward_scan<true>(lds[s][0], lds[s][1], lds[s][2], a.w, a.out + (s0 + s) * cnn_out_dim(a.kind, a.head), a.kind,
+                     a.head, lane, kCnnLanes);
 }
 
 }  // namespace auv

@@ -5,18 +5,22 @@
 //            sin/cos, own velocity, navigation features, along-track progress,
 //            goal / truncation flags, the scene-independent part of the reward.
 // k_sense    one workgroup per tile of envs, reading their scene ONCE from HBM:
-//   1. (step only) advances the constant-velocity obstacles, writes them back;
-//   2. makes every primitive vessel-relative in LDS, with its candidate ray
-//      interval (auv_lidar_raster.hpp) and, per polygon edge, its distance to
-//      the vessel and its crossing-number bit; circle threads also finish
-//      their obstacle's metadata and risk, two edge threads per polygon
-//      compute its bearing and course;
-//   3. per polygon: signed hull distance from its edges, metadata, risk;
-//      per env: nearest obstacle, collision, reward, done;
-//   4. LiDAR: dense (primitive, ray) pair list, exact fp64 tests, LDS atomic
-//      min per ray, id resolution, then 16 B per ray written out.
-// Results are bit-identical to k_dynamics(advance) + k_encounter + k_lidar.
+//   1. one thread per primitive (circle / polygon edge): (step only) advances
+//      the constant-velocity obstacle and writes it back; makes the primitive
+//      vessel-relative in LDS; derives its candidate ray interval
+//      (auv_lidar_raster.hpp) and appends its (primitive, ray) pairs to the
+//      tile's pair list; per edge also the distance to the vessel and the
+//      crossing-number bit;
+//   2. per obstacle, on three waves in parallel: signed hull distance,
+//      metadata, risk; per env: nearest obstacle, collision, reward, done;
+//   3. LiDAR, in the same barrier interval as 2: exact fp64 test of every
+//      listed pair, LDS atomic min per ray, then id resolution;
+//   4. 16 B per ray written out; with a network attached, its forward pass on
+//      the closeness values still in LDS.
+// Results are bit-identical to k_dynamics(advance) + k_encounter + k_lidar
+// (+ k_cnn).
 #pragma once
+#include "auv_cnn.hpp"
 #include "auv_lidar_raster.hpp"
 
 namespace auv {
@@ -122,6 +126,11 @@ struct SenseArgs {
     double dt, sensor_range, vessel_radius;
     double w_d, w_c, t_c;
     double rw_collision, rw_goal;
+    // LiDAR-CNN evaluated in the epilogue (cnn_w == nullptr: none); needs
+    // R == kCnnLen and cnn_fits_sense_kernel(cnn_kind)
+    const float* cnn_w;
+    float* cnn_out;  // [V, cnn_out_dim]
+    int cnn_kind, cnn_head;
 };
 
 struct SenseLayout {
@@ -132,7 +141,13 @@ struct SenseLayout {
 //   env[TE][2] cos psi, sin psi       circ[TE*C][3] mx,my,cc       seg[TE*S][5] ax,ay,ex,ey,nt
 //   best[TE*R] u64                    obst[TE*O][8] mx,my,rvx,rvy,bearing,course,dist,-
 //   edist[TE*S] f64   meta[NP] int4   offs[NP+1]   ids[TE*R]   pairs[cap]   ecross[TE*S]   wsum[8]
-__host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P, int NV, int cap) {
+// With a network evaluated in-kernel (cnn_kind >= 0) its weights and two
+// activation buffers per env reuse the bytes in front of best[], which are
+// dead by then; the front is padded when it is smaller than that.
+__host__ __device__ inline size_t sense_cnn_bytes(int TE, int cnn_kind) {
+    return cnn_kind < 0 ? 0 : ((size_t)((cnn_n_weights(cnn_kind) + 3) & ~3) + (size_t)TE * 2 * cnn_buf_floats(cnn_kind)) * 4;
+}
+__host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P, int NV, int cap, int cnn_kind) {
     SenseLayout L;
     const size_t S = (size_t)P * NV, O = (size_t)C + P;
     const size_t NP = (size_t)TE * ((size_t)C + S);
@@ -140,6 +155,8 @@ __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P,
     L.env = o; o += (size_t)TE * 2 * 8;
     L.circ = o; o += (size_t)TE * C * 3 * 8;
     L.seg = o; o += (size_t)TE * S * 5 * 8;
+    const size_t act = sense_cnn_bytes(TE, cnn_kind);
+    o = o < act ? act : o;
     L.best = o; o += (size_t)TE * R * 8;
     L.obst = o; o += (size_t)TE * O * 8 * 8;
     L.edist = o; o += (size_t)TE * S * 8;
@@ -250,7 +267,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
     const int S = P * NV;
     const int TE = a.TE;
     const int cap = a.cap;
-    const SenseLayout L = sense_layout(TE, R, C, P, NV, cap);
+    const SenseLayout L = sense_layout(TE, R, C, P, NV, cap, a.cnn_w ? a.cnn_kind : -1);
     double* env = reinterpret_cast<double*>(lds_raw + L.env);
     double* circ = reinterpret_cast<double*>(lds_raw + L.circ);
     double* seg = reinterpret_cast<double*>(lds_raw + L.seg);
@@ -637,13 +654,34 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         }
     }
 
-    // ---- phase 4: 16 B per ray, coalesced
+    // ---- phase 4: 16 B per ray, coalesced; the attached network's weights
+    // come in meanwhile
+    float* cnn_lds = reinterpret_cast<float*>(lds_raw);  // weights, then 2 activation buffers per env
+    const int n_w = a.cnn_w ? cnn_n_weights(a.cnn_kind) : 0;
+    float w_mine = 0.f;
+    if (tid < n_w) w_mine = a.cnn_w[tid];
     for (int f = tid; f < ne * R; f += nthr) {
         const double t = __longlong_as_double((long long)best[f]);
         const size_t out = (size_t)e0 * R + f;
+        const float close = (float)(1.0 - t / range);
         a.ranges[out] = t;
         a.hit[out] = (int)ids[f];
-        a.perception[out] = (float)(1.0 - t / range);
+        a.perception[out] = close;
+        if (a.cnn_w) reinterpret_cast<float*>(ids)[f] = close;  // the id slot becomes the network's input
+    }
+    if (a.cnn_w) {
+        if (tid < n_w) cnn_lds[tid] = w_mine;
+        for (int i = tid + nthr; i < n_w; i += nthr) cnn_lds[i] = a.cnn_w[i];
+        __syncthreads();
+        // one wave per scan; every output element is summed by one lane in the
+        // order k_cnn uses, so the values are the same
+        const int od = cnn_out_dim(a.cnn_kind, a.cnn_head);
+        const int nb = cnn_buf_floats(a.cnn_kind);
+        float* act = cnn_lds + ((n_w + 3) & ~3);
+        for (int s = tid >> 6; s < ne; s += nthr >> 6)
+            cnn_forward_scan<false>(reinterpret_cast<const float*>(ids) + (size_t)s * R, act + (size_t)s * 2 * nb,
+                                    act + ((size_t)s * 2 + 1) * nb, cnn_lds, a.cnn_out + (size_t)(e0 + s) * od,
+                                    a.cnn_kind, a.cnn_head, lane, 64);
     }
     AUV_STAMP(9);
 }

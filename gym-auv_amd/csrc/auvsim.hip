@@ -70,7 +70,11 @@ struct auv_sim {
     size_t lidar_lds = 0, enc_lds = 0;
     int lidar_mode = AUV_LIDAR_RASTER;
     int raster_te = 1, raster_cap = 2048, sense_block = 256;
+    int raster_want = 0;  // envs per workgroup asked for (0 = automatic)
     size_t raster_lds = 0;
+    // attached LiDAR-CNN: a private copy of its weights, evaluated with every sensing pass
+    float* cnn_w = nullptr;
+    int cnn_kind = 0, cnn_head = 0;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;  // kProfRing * 4
@@ -147,7 +151,9 @@ int pair_cap(const Dims& d, int te) {
 void set_raster_tile(auv_sim* h, int want) {
     const Dims& d = h->d;
     const int S = d.P * d.NV;
-    auto bytes = [&](int te) { return sense_layout(te, d.R, d.C, d.P, d.NV, pair_cap(d, te)).total; };
+    const int cf = (h->cnn_w && cnn_fits_sense_kernel(h->cnn_kind)) ? h->cnn_kind : -1;
+    auto bytes = [&](int te) { return sense_layout(te, d.R, d.C, d.P, d.NV, pair_cap(d, te), cf).total; };
+    h->raster_want = want;
     int te = want;
     if (te <= 0) {
         te = 16;
@@ -156,10 +162,10 @@ void set_raster_tile(auv_sim* h, int want) {
     }
     while (te > 1 && bytes(te) > kLdsMax) te >>= 1;
     int cap = pair_cap(d, te);
-    while (cap > 256 && sense_layout(te, d.R, d.C, d.P, d.NV, cap).total > kLdsMax) cap >>= 1;
+    while (cap > 256 && sense_layout(te, d.R, d.C, d.P, d.NV, cap, cf).total > kLdsMax) cap >>= 1;
     h->raster_te = te;
     h->raster_cap = cap;
-    h->raster_lds = sense_layout(te, d.R, d.C, d.P, d.NV, cap).total;
+    h->raster_lds = sense_layout(te, d.R, d.C, d.P, d.NV, cap, cf).total;
     // the pair list packs (primitive, ray offset) into 16 bits each
     if ((long long)te * (d.C + S) > 65535 || d.R > 65535) h->raster_lds = (size_t)1 << 30;
 }
@@ -189,6 +195,20 @@ void choose_geometry(auv_sim* h) {
     if (eb < 1) eb = 1;
     h->enc_eb = eb;
     h->enc_lds = (size_t)eb * O * sizeof(double);
+}
+
+// the attached network as a launch of its own, on the perception buffer
+int launch_cnn(auv_sim* h, hipStream_t st) {
+    CnnArgs ca;
+    ca.scans = bp<float>(h, AUV_BUF_PERCEPTION);
+    ca.w = h->cnn_w;
+    ca.out = bp<float>(h, AUV_BUF_CNN_OUT);
+    ca.B = h->d.V;
+    ca.kind = h->cnn_kind;
+    ca.head = h->cnn_head;
+    hipLaunchKernelGGL(k_cnn, dim3((unsigned)((h->d.V + kCnnScans - 1) / kCnnScans)), dim3(256), 0, st, ca);
+    HIP_TRY(h, hipGetLastError());
+    return AUV_OK;
 }
 
 // Fused path: k_vessel (integration when do_step, then the vessel-only
@@ -258,9 +278,18 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.t_c = h->cfg.risk[2];
     sa.rw_collision = h->cfg.reward[1];
     sa.rw_goal = h->cfg.reward[2];
+    const bool cnn_inside = h->cnn_w && cnn_fits_sense_kernel(h->cnn_kind);
+    sa.cnn_w = cnn_inside ? h->cnn_w : nullptr;
+    sa.cnn_out = bp<float>(h, AUV_BUF_CNN_OUT);
+    sa.cnn_kind = h->cnn_kind;
+    sa.cnn_head = h->cnn_head;
     const int blocks = (d.V + h->raster_te - 1) / h->raster_te;
     hipLaunchKernelGGL(k_sense, dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
     HIP_TRY(h, hipGetLastError());
+    if (h->cnn_w && !cnn_inside) {
+        int rc = launch_cnn(h, st);  // the large network keeps a launch of its own
+        if (rc) return rc;
+    }
     if (ev) HIP_TRY(h, hipEventRecord(ev[3], st));
     return AUV_OK;
 }
@@ -328,6 +357,10 @@ int launch_sense(auv_sim* h, hipStream_t st, hipEvent_t* ev, int is_step) {
     const int lid_blocks = (d.V + h->lidar_te - 1) / h->lidar_te;
     hipLaunchKernelGGL(k_lidar, dim3(lid_blocks), dim3(h->lidar_block), h->lidar_lds, st, la);
     HIP_TRY(h, hipGetLastError());
+    if (h->cnn_w) {
+        int rc = launch_cnn(h, st);
+        if (rc) return rc;
+    }
     if (ev) HIP_TRY(h, hipEventRecord(ev[3], st));
     return AUV_OK;
 }
@@ -483,6 +516,7 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     chk(alloc_buf(h, AUV_BUF_CIRCLES, AUV_F64, {V, C, 5}));
     chk(alloc_buf(h, AUV_BUF_POLY_POSE, AUV_F64, {V, P, 6}));
     chk(alloc_buf(h, AUV_BUF_REWARD, AUV_F64, {V}));
+    chk(alloc_buf(h, AUV_BUF_CNN_OUT, AUV_F32, {V, 12}));  // widest head; the shape follows the attached network
     chk(alloc_raw(h, &h->poly_verts, (size_t)V * P * NV * 2));
     chk(alloc_raw(h, &h->poly_nv, (size_t)V * P));
     chk(alloc_raw(h, &h->poly_heading, (size_t)V * P));
@@ -521,7 +555,7 @@ void auv_destroy(auv_handle h) {
     for (auto& b : h->buf)
         if (b.ptr) (void)hipFree(b.ptr);
     void* raw[] = {h->poly_verts, h->poly_nv, h->poly_heading, h->path, h->ray_dirs, h->init_stage, h->mask_stage,
-                   h->circles0, h->poly_pose0, h->envrec};
+                   h->circles0, h->poly_pose0, h->envrec, h->cnn_w};
     for (void* p : raw)
         if (p) (void)hipFree(p);
     delete h;
@@ -891,6 +925,41 @@ int auv_cnn_forward(auv_cnn_handle c, const float* scans, int64_t n_scans, int32
     hipLaunchKernelGGL(k_cnn, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cnn_fail(c, AUV_ERR_DEVICE, "k_cnn launch failed: %s", hipGetErrorString(e));
+    return AUV_OK;
+}
+
+int auv_attach_cnn(auv_handle h, auv_cnn_handle c, int32_t head) {
+    if (!h) return AUV_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());  // no launch may still be using the old weights or tile
+    BufDesc& b = h->buf[AUV_BUF_CNN_OUT];
+    if (!c) {
+        if (h->cnn_w) (void)hipFree(h->cnn_w);
+        h->cnn_w = nullptr;
+        set_raster_tile(h, h->raster_want);
+        return AUV_OK;
+    }
+    if (head != AUV_CNN_FEATURES && head != AUV_CNN_RISK)
+        return fail(h, AUV_ERR_ARG, "auv_attach_cnn: unknown head %d", head);
+    if (h->d.R != kCnnLen)
+        return fail(h, AUV_ERR_ARG, "auv_attach_cnn: the networks take %d-ray scans, this batch has %d", kCnnLen, h->d.R);
+    if (c->device != h->device)
+        return fail(h, AUV_ERR_ARG, "auv_attach_cnn: network lives on device %d, batch on %d", c->device, h->device);
+    float* w = nullptr;
+    const size_t nb = (size_t)cnn_n_weights(c->kind) * sizeof(float);
+    HIP_TRY(h, hipMalloc((void**)&w, nb));
+    if (hipMemcpy(w, c->w, nb, hipMemcpyDeviceToDevice) != hipSuccess) {
+        (void)hipFree(w);
+        return fail(h, AUV_ERR_DEVICE, "auv_attach_cnn: weight copy failed");
+    }
+    if (h->cnn_w) (void)hipFree(h->cnn_w);
+    h->cnn_w = w;
+    h->cnn_kind = c->kind;
+    h->cnn_head = head;
+    b.shape[1] = cnn_out_dim(c->kind, head);
+    b.bytes = (size_t)b.shape[0] * (size_t)b.shape[1] * sizeof(float);
+    set_raster_tile(h, h->raster_want);  // the activation buffers change the LDS image
+    if (h->raster_lds > kLdsMax) h->lidar_mode = AUV_LIDAR_ALL_PAIRS;
     return AUV_OK;
 }
 

@@ -27,7 +27,7 @@ def _ptr(a):
 
 
 def _stream_handle(stream):
-    """Raw hipStream_t of a torch stream, an int, or None (handle's own)."""
+    """Raw hipStream_t of a torch stream, an int, or None (HIP's default stream)."""
     if stream is None:
         return None
     if isinstance(stream, int):
@@ -167,6 +167,12 @@ class AuvSim:
 
     def set_option(self, key: int, value: int):
         self._check(self._lib.auv_set_option(self._h, int(key), int(value)))
+
+    def attach_cnn(self, cnn, head: str = "features"):
+        """Evaluate `head` of a `cnn.LidarCNN` inside every sensing pass; the
+        result is the buffer "cnn_out" [V,out_dim].  None detaches."""
+        from .cnn import HEADS
+        self._check(self._lib.auv_attach_cnn(self._h, None if cnn is None else cnn._h, HEADS[head]))
 
     # -- profiling ----------------------------------------------------------
     def profile(self, on: bool):

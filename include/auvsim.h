@@ -96,7 +96,8 @@ typedef enum auv_buffer {
     AUV_BUF_CIRCLES = 18,    /* f64 [V,C,5] cx,cy,rad,vx,vy */
     AUV_BUF_POLY_POSE = 19,  /* f64 [V,P,6] X,Y,cos h,sin h,vx,vy */
     AUV_BUF_REWARD = 20,     /* f64 [V]   reward of the last step (0 after reset) */
-    AUV_BUF_COUNT = 21
+    AUV_BUF_CNN_OUT = 21,    /* f32 [V,out_dim] output of the attached network (auv_attach_cnn); zeros, out_dim 12, before */
+    AUV_BUF_COUNT = 22
 } auv_buffer;
 
 /* Tunables (auv_set_option).  Both LiDAR kernels produce identical bits; the
@@ -217,6 +218,17 @@ void auv_cnn_destroy(auv_cnn_handle c);
 int auv_cnn_forward(auv_cnn_handle c, const float* scans, int64_t n_scans, int32_t head, float* out,
                     void* stream);
 const char* auv_cnn_last_error(auv_cnn_handle c);
+
+/* Attach a network to a batch: from then on every sensing pass (auv_reset,
+ * auv_step*, auv_sense) also evaluates `head` of the network on the fresh
+ * scans and leaves the result in AUV_BUF_CNN_OUT, f32 [V,out_dim].  On the
+ * rasterising path this happens inside the sensing kernel, on the closeness
+ * values it still holds on chip; results equal auv_cnn_forward on
+ * AUV_BUF_PERCEPTION bit for bit.  The batch keeps its own copy of the weights
+ * (`c` may be destroyed afterwards); c == NULL detaches.  Needs n_rays == 180.
+ * Synchronises the device.  Replaces the extractor's per-step CNN call,
+ * radarCNN.py:270-280. */
+int auv_attach_cnn(auv_handle h, auv_cnn_handle c, int32_t head);
 
 #ifdef __cplusplus
 }
