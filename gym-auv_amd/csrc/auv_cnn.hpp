@@ -37,16 +37,25 @@ struct CnnArgs {
     int kind, head;
 };
 
+// A layer works on `ns` scans at once: scan s reads in + s*in_stride and writes
+// out + s*out_stride; the ns*outputs-per-scan output elements are dealt to
+// `n_workers` threads (this one is `worker`).  Every element is accumulated by
+// one thread in a fixed order, so results do not depend on the dealing.
+//
 // out[co][lo] = act(b[co] + sum_ci sum_k w[co][ci][k] * in[ci][(pos*stride + k - pad) mod L]),
 // optionally followed by MaxPool1d(2, 2, ceil_mode=True) fused into the store
 template <bool RELU, bool POOL>
-__device__ __forceinline__ int conv_layer(const float* in, float* out, const float* w, const float* b, int Cin,
-                                          int Cout, int L, int K, int stride, int pad, int lane, int n_lanes) {
+__device__ __forceinline__ int conv_layer(const float* in, int in_stride, float* out, int out_stride, int ns,
+                                          const float* w, const float* b, int Cin, int Cout, int L, int K, int stride,
+                                          int pad, int worker, int n_workers) {
     const int Lc = (L + 2 * pad - K) / stride + 1;
     const int Lo = POOL ? (Lc + 1) / 2 : Lc;
-    for (int idx = lane; idx < Cout * Lo; idx += n_lanes) {
-        const int co = idx / Lo;
-        const int lo = idx - co * Lo;
+    const int per_scan = Cout * Lo;
+    for (int idx = worker; idx < ns * per_scan; idx += n_workers) {
+        const int s = idx / per_scan;
+        const int el = idx - s * per_scan;
+        const int co = el / Lo;
+        const int lo = el - co * Lo;
         float best = 0.f;
         const int n_pos = (POOL && 2 * lo + 1 < Lc) ? 2 : 1;
         for (int j = 0; j < n_pos; ++j) {
@@ -54,7 +63,7 @@ __device__ __forceinline__ int conv_layer(const float* in, float* out, const flo
             float acc = b[co];
             for (int ci = 0; ci < Cin; ++ci) {
                 const float* wr = w + ((size_t)co * Cin + ci) * K;
-                const float* xr = in + ci * L;
+                const float* xr = in + (size_t)s * in_stride + ci * L;
                 int p = pos * stride - pad;
                 p = p < 0 ? p + L : p;
 #pragma unroll 9
@@ -66,99 +75,127 @@ __device__ __forceinline__ int conv_layer(const float* in, float* out, const flo
             if (RELU) acc = acc > 0.f ? acc : 0.f;
             best = (j == 0 || acc > best) ? acc : best;
         }
-        out[idx] = best;
+        out[(size_t)s * out_stride + el] = best;
     }
     return Lo;
 }
 
 template <bool RELU>
-__device__ __forceinline__ void linear_layer(const float* in, float* out, const float* w, const float* b, int n_in,
-                                             int n_out, int lane, int n_lanes) {
-    for (int o = lane; o < n_out; o += n_lanes) {
+__device__ __forceinline__ void linear_layer(const float* in, int in_stride, float* out, int out_stride, int ns,
+                                             const float* w, const float* b, int n_in, int n_out, int worker,
+                                             int n_workers) {
+    for (int idx = worker; idx < ns * n_out; idx += n_workers) {
+        const int s = idx / n_out;
+        const int o = idx - s * n_out;
+        const float* x = in + (size_t)s * in_stride;
         float acc = 0.f;
 #pragma unroll 4
-        for (int i = 0; i < n_in; ++i) acc += in[i] * w[(size_t)o * n_in + i];
+        for (int i = 0; i < n_in; ++i) acc += x[i] * w[(size_t)o * n_in + i];
         acc += b[o];
         if (RELU) acc = acc > 0.f ? acc : 0.f;
-        out[o] = acc;
+        out[(size_t)s * out_stride + o] = acc;
     }
 }
 
-// the lanes of a scan live in one wave: a wave-level LDS fence is enough
-__device__ __forceinline__ void scan_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// Between layers: the workers of one scan group either sit in one wave (a
+// wave-level LDS fence is enough) or are the whole workgroup.
+template <bool BLOCK>
+__device__ __forceinline__ void layer_sync() {
+    if (BLOCK) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
 // LDS floats per activation buffer of one scan (two buffers are needed)
 __host__ __device__ inline int cnn_buf_floats(int kind) { return kind == CNN_DEEP ? kCnnBuf : 40; }
 // the two small networks can run inside the sensing kernel, weights staged in LDS
 __host__ __device__ inline bool cnn_fits_sense_kernel(int kind) { return kind == CNN_SHALLOW || kind == CNN_2DEEP; }
 
-// Forward pass of one scan by `nl` lanes of one wave (lane = 0..nl-1): x = the
-// 180 closeness values in LDS, p and q = two activation buffers of
-// cnn_buf_floats(kind) floats in LDS, out = the scan's row of the result in
-// global memory.  Every output element is accumulated by one lane in a fixed
-// order, so the result does not depend on nl.  WITH_DEEP = false leaves the
-// largest network out of the instantiation (kind must not be CNN_DEEP then).
-template <bool WITH_DEEP>
-__device__ __forceinline__ void cnn_forward_scan(const float* x, float* p, float* q, const float* w, float* out,
-                                                 int kind, int head, int lane, int nl) {
+// Forward pass of `ns` scans by `n_workers` cooperating threads.  Scan s has
+// its 180 closeness values at x + s*x_stride and two activation buffers of
+// cnn_buf_floats(kind) floats at p + s*a_stride and q + s*a_stride (all LDS);
+// its row of the result goes to out + s*out_dim (global).  BLOCK: the workers
+// are the whole workgroup (all of its threads must call), else lanes of one
+// wave.  WITH_DEEP = false leaves the largest network out of the instantiation
+// (kind must not be CNN_DEEP then).
+template <bool WITH_DEEP, bool BLOCK>
+__device__ __forceinline__ void cnn_forward(const float* x, int x_stride, float* p, float* q, int a_stride, int ns,
+                                            const float* w, float* out, int kind, int head, int worker,
+                                            int n_workers) {
     const float* res = p;
     int n_res = 0;
+#define AUV_CONV(RELU, POOL, IN, IN_STRIDE, OUT, ...) \
+    conv_layer<RELU, POOL>(IN, IN_STRIDE, OUT, a_stride, ns, __VA_ARGS__, worker, n_workers)
+#define AUV_LIN(RELU, IN, OUT, ...) linear_layer<RELU>(IN, a_stride, OUT, a_stride, ns, __VA_ARGS__, worker, n_workers)
     if (kind == CNN_SHALLOW) {
         // w: conv.weight[45] conv.bias[1] linear.weight[12] linear.bias[1]
         if (head == HEAD_FEATURES) {
-            conv_layer<false, false>(x, p, w, w + 45, 1, 1, kCnnLen, 45, 15, 15, lane, nl);
+            AUV_CONV(false, false, x, x_stride, p, w, w + 45, 1, 1, kCnnLen, 45, 15, 15);
             res = p;
             n_res = 12;
         } else {
-            conv_layer<true, false>(x, p, w, w + 45, 1, 1, kCnnLen, 45, 15, 15, lane, nl);
-            scan_sync();
-            linear_layer<true>(p, q, w + 46, w + 58, 12, 1, lane, nl);
+            AUV_CONV(true, false, x, x_stride, p, w, w + 45, 1, 1, kCnnLen, 45, 15, 15);
+            layer_sync<BLOCK>();
+            AUV_LIN(true, p, q, w + 46, w + 58, 12, 1);
             res = q;
             n_res = 1;
         }
     } else if (!WITH_DEEP || kind == CNN_2DEEP) {
         // w: c1.w[3*45] c1.b[3] c2.w[2*3*3] c2.b[2] c3.w[1*2*3] c3.b[1] lin.w[12] lin.b[1]
-        conv_layer<true, false>(x, p, w, w + 135, 1, 3, kCnnLen, 45, 15, 15, lane, nl);
-        scan_sync();
-        conv_layer<true, false>(p, q, w + 138, w + 156, 3, 2, 12, 3, 1, 1, lane, nl);
-        scan_sync();
-        conv_layer<false, false>(q, p, w + 158, w + 164, 2, 1, 12, 3, 1, 1, lane, nl);
+        AUV_CONV(true, false, x, x_stride, p, w, w + 135, 1, 3, kCnnLen, 45, 15, 15);
+        layer_sync<BLOCK>();
+        AUV_CONV(true, false, p, a_stride, q, w + 138, w + 156, 3, 2, 12, 3, 1, 1);
+        layer_sync<BLOCK>();
+        AUV_CONV(false, false, q, a_stride, p, w + 158, w + 164, 2, 1, 12, 3, 1, 1);
         res = p;
         n_res = 12;
         if (head == HEAD_RISK) {
-            scan_sync();
-            linear_layer<true>(p, q, w + 165, w + 177, 12, 1, lane, nl);
+            layer_sync<BLOCK>();
+            AUV_LIN(true, p, q, w + 165, w + 177, 12, 1);
             res = q;
             n_res = 1;
         }
     } else if constexpr (WITH_DEEP) {
         // w: c1.w[2*1*9] b[2] c2.w[4*2*9] b[4] c3.w[4*4*9] b[4] c4.w[6*4*9] b[6]
         //    l1.w[40*72] b[40] l2.w[8*40] b[8] l3.w[8] b[1]
-        int L = conv_layer<true, true>(x, p, w, w + 18, 1, 2, kCnnLen, 9, 1, 4, lane, nl);       // 2 x 90
-        scan_sync();
-        L = conv_layer<true, true>(p, q, w + 20, w + 92, 2, 4, L, 9, 1, 4, lane, nl);            // 4 x 45
-        scan_sync();
-        L = conv_layer<true, true>(q, p, w + 96, w + 240, 4, 4, L, 9, 1, 4, lane, nl);           // 4 x 23
-        scan_sync();
-        L = conv_layer<true, true>(p, q, w + 244, w + 460, 4, 6, L, 9, 1, 4, lane, nl);          // 6 x 12
-        scan_sync();
-        linear_layer<true>(q, p, w + 466, w + 3346, 72, 40, lane, nl);
-        scan_sync();
-        linear_layer<false>(p, q, w + 3386, w + 3706, 40, 8, lane, nl);
+        int L = AUV_CONV(true, true, x, x_stride, p, w, w + 18, 1, 2, kCnnLen, 9, 1, 4);  // 2 x 90
+        layer_sync<BLOCK>();
+        L = AUV_CONV(true, true, p, a_stride, q, w + 20, w + 92, 2, 4, L, 9, 1, 4);       // 4 x 45
+        layer_sync<BLOCK>();
+        L = AUV_CONV(true, true, q, a_stride, p, w + 96, w + 240, 4, 4, L, 9, 1, 4);      // 4 x 23
+        layer_sync<BLOCK>();
+        L = AUV_CONV(true, true, p, a_stride, q, w + 244, w + 460, 4, 6, L, 9, 1, 4);     // 6 x 12
+        layer_sync<BLOCK>();
+        AUV_LIN(true, q, p, w + 466, w + 3346, 72, 40);
+        layer_sync<BLOCK>();
+        AUV_LIN(false, p, q, w + 3386, w + 3706, 40, 8);
         res = q;
         n_res = 8;
         if (head == HEAD_RISK) {
-            scan_sync();
+            layer_sync<BLOCK>();
             // ReLU on the 8 features, then Linear(8 -> 1) + ReLU
-            if (lane < 8) p[lane] = q[lane] > 0.f ? q[lane] : 0.f;
-            scan_sync();
-            linear_layer<true>(p, q + 8, w + 3714, w + 3722, 8, 1, lane, nl);
+            for (int i = worker; i < ns * 8; i += n_workers) {
+                const int s = i >> 3, o = i & 7;
+                const float v = q[(size_t)s * a_stride + o];
+                p[(size_t)s * a_stride + o] = v > 0.f ? v : 0.f;
+            }
+            layer_sync<BLOCK>();
+            AUV_LIN(true, p, q + 8, w + 3714, w + 3722, 8, 1);
             res = q + 8;
             n_res = 1;
         }
     }
-    scan_sync();
-    for (int i = lane; i < n_res; i += nl) out[i] = res[i];
+#undef AUV_CONV
+#undef AUV_LIN
+    layer_sync<BLOCK>();
+    for (int i = worker; i < ns * n_res; i += n_workers) {
+        const int s = i / n_res;
+        const int o = i - s * n_res;
+        out[(size_t)s * n_res + o] = res[(size_t)s * a_stride + o];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_cnn(CnnArgs a) {
@@ -172,11 +209,12 @@ __global__ __launch_bounds__(256) void k_cnn(CnnArgs a) {
         lds[s][0][i - s * kCnnLen] = a.scans[s0 * kCnnLen + i];
     }
     __syncthreads();
+    // 16 lanes per scan, one scan per lane group
     const int s = tid / kCnnLanes;
     const int lane = tid - s * kCnnLanes;
     if (s >= ns) return;
-    cnn_forward_scan<true>(lds[s][0], lds[s][1], lds[s][2], a.w, a.out + (s0 + s) * cnn_out_dim(a.kind, a.head), a.kind,
-                     a.head, lane, kCnnLanes);
+    cnn_forward<true, false>(lds[s][0], 0, lds[s][1], lds[s][2], 0, 1, a.w,
+                             a.out + (s0 + s) * cnn_out_dim(a.kind, a.head), a.kind, a.head, lane, kCnnLanes);
 }
 
 }  // namespace auv

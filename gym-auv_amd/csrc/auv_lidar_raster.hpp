@@ -64,8 +64,16 @@ __device__ __forceinline__ int2 make_interval(float lo, float hi, int R, float m
     const int ilo = (int)floorf(lo - margin);
     const int ihi = (int)ceilf(hi + margin);
     int cnt = ihi - ilo + 1;
-    int first = ilo % R;
-    if (first < 0) first += R;
+    // ilo mod R; lo is never more than half a scan below -1, so for all but
+    // the tiniest scans two conditional corrections replace the division
+    int first;
+    if (R < 8) {
+        first = ilo % R;
+        if (first < 0) first += R;
+    } else {
+        first = ilo < 0 ? ilo + R : ilo;
+        first = first >= R ? first - R : first;
+    }
     if (cnt >= R) {
         cnt = R;
         first = 0;

@@ -124,6 +124,7 @@ struct SenseArgs {
     int32_t* min_idx;
     double* reward;
     double dt, sensor_range, vessel_radius;
+    double inv_range;  // 1 / sensor_range, rounded to nearest
     double w_d, w_c, t_c;
     double rw_collision, rw_goal;
     // LiDAR-CNN evaluated in the epilogue (cnn_w == nullptr: none); needs
@@ -209,13 +210,27 @@ __device__ __forceinline__ PairHit pair_test(unsigned int pr, int R, int n_circ,
     return h;
 }
 
+// t / b, correctly rounded, for a divisor whose correctly rounded reciprocal
+// y = RN(1/b) is known (b > 0, t >= 0): t*y refined twice with exact FMA
+// residuals; the second refinement starts from a faithful quotient, which makes
+// its result the rounded true quotient.  Quotients so small that a residual
+// could underflow take the divider.
+__device__ __forceinline__ double div_by_const(double t, double b, double y) {
+    if (__builtin_expect(!(t >= 0x1p-900) && t != 0.0, 0)) return t / b;
+    double q = t * y;
+    double r = __builtin_fma(-q, b, t);
+    q = __builtin_fma(r, y, q);
+    r = __builtin_fma(-q, b, t);
+    return __builtin_fma(r, y, q);
+}
+
 // default risk index of one obstacle (m = centre relative to the vessel, rv =
 // relative velocity, dist = signed hull distance)
 __device__ __forceinline__ double risk_index(double mx, double my, double rvx, double rvy, double vv, double dist,
-                                             double range, double w_d, double w_c, double t_c) {
+                                             double range, double inv_range, double w_d, double w_c, double t_c) {
     const double d = dist < 0.0 ? 0.0 : dist;
     const bool inrange = d < range;
-    const double fd = 1.0 - (inrange ? d : 0.0) / range;
+    const double fd = 1.0 - div_by_const(inrange ? d : 0.0, range, inv_range);
     const double term_d = w_d * (fd * fd);
     const double closing = 0.0 - (mx * rvx + my * rvy);
     const bool has_c = (vv > 0.0) && (closing > 0.0);
@@ -223,7 +238,7 @@ __device__ __forceinline__ double risk_index(double mx, double my, double rvx, d
     const double qx = mx + rvx * tcpa;
     const double qy = my + rvy * tcpa;
     const double dcpa = __builtin_sqrt(qx * qx + qy * qy);
-    const double fc = 1.0 - (dcpa < range ? dcpa : range) / range;
+    const double fc = 1.0 - div_by_const(dcpa < range ? dcpa : range, range, inv_range);
     const double term_c = (w_c * (fc * fc)) * (t_c / (t_c + tcpa));
     const double rr = term_d + (has_c ? term_c : 0.0);
     return inrange ? rr : 0.0;
@@ -303,10 +318,13 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         wsum[6] = 0;
         wsum[7] = 0;
     }
-    for (int el = tid; el < ne; el += nthr) {
-        const double* er = a.envrec + (size_t)(e0 + el) * ER_COUNT;
-        env[el * 2] = er[ER_COS];
-        env[el * 2 + 1] = er[ER_SIN];
+    // heading sin/cos of the tile's vessels: requested now, filed at the end of
+    // phase 1, so that the first barrier does not wait for global memory
+    double env_c = 0.0, env_s = 0.0;
+    if (tid < ne) {  // ne <= 64 <= nthr
+        const double* er = a.envrec + (size_t)(e0 + tid) * ER_COUNT;
+        env_c = er[ER_COS];
+        env_s = er[ER_SIN];
     }
     const unsigned long long range_bits = (unsigned long long)__double_as_longlong(range);
     for (int f = tid; f < ne * R; f += nthr) {
@@ -430,14 +448,14 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
             }
             const double qx = ax + tp * ex;
             const double qy = ay + tp * ey;
-            dd = __builtin_sqrt(qx * qx + qy * qy);
+            dd = qx * qx + qy * qy;  // squared: the one square root per polygon is taken in phase 2
             const bool up = (ay <= 0.0) && (by > 0.0) && (nt > 0.0);
             const bool dn = (by <= 0.0) && (ay > 0.0) && (nt < 0.0);
             cross = (up || dn) ? 1 : 0;
             // candidate rays: the arc between the bearings of the two endpoints
             const float fax = (float)ax, fay = (float)ay, fex = (float)ex, fey = (float)ey;
             const float fbx = fax + fex, fby = fay + fey;
-            const float dmin = (float)dd;
+            const float dmin = sqrtf((float)dd);
             const float aa = fax * fax + fay * fay, bb = fbx * fbx + fby * fby;
             if (dmin > frange) {
                 // wholly beyond sensor range: stays empty
@@ -474,26 +492,52 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
                 pairs[top - 1 - kk] = ((unsigned int)(n_circ + i) << 16) | (unsigned int)kk;
         }
     }
+    if (tid < ne) {
+        env[tid * 2] = env_c;
+        env[tid * 2 + 1] = env_s;
+    }
     AUV_STAMP(2);
     __syncthreads();
     AUV_STAMP(3);
     const int n_cp = wsum[6], n_ep = wsum[7];
+#ifdef AUV_PHASE_STAMPS
+    if (g_stamps && tid == 0) {
+        g_stamps[(size_t)blockIdx.x * 64 + 14] = n_cp;
+        g_stamps[(size_t)blockIdx.x * 64 + 15] = n_ep;
+    }
+#endif
     const int total = n_cp + n_ep;
     const bool fits = total <= cap;
 
-    // ---- phase 2: obstacle-level outputs.  Three independent tasks per
+    // ---- phase 2: obstacle-level outputs.  Four independent tasks per
     // obstacle, each on a wave of its own so that no wave runs two of the long
     // fp64 chains back to back: 0 = distance (polygons: from their edges; also
-    // the deferred write-back of the advanced position), relative speed, risk
-    // and the per-env summary; 1 = bearing; 2 = course.
+    // the deferred write-back of the advanced position), relative speed and
+    // the per-env summary; 1 = bearing; 2 = course; 3 = risk.
     {
         const int n_waves = nthr >> 6;
         const int wave = tid >> 6;
         const int n_obst = ne * O;
+        // signed hull distance less the vessel radius; polygons: nearest edge
+        // (sqrt of the smallest squared distance), sign from the crossing parity
+        auto hull_distance = [&](const double* ob, int el, int o) -> double {
+            if (o < C) return ob[OB_DIST];
+            const int s0 = el * S + (o - C) * NV;
+            const int nv = ecross[s0] >> 1;
+            double dmin2 = __builtin_inf();
+            int par = 0;
+            for (int k = 0; k < nv; ++k) {
+                const double d2 = edist[s0 + k];
+                dmin2 = d2 < dmin2 ? d2 : dmin2;
+                par ^= ecross[s0 + k] & 1;
+            }
+            const double dmin = __builtin_sqrt(dmin2);
+            return nv > 0 ? (par ? -dmin : dmin) - a.vessel_radius : __builtin_inf();
+        };
         // when an env's obstacles sit in an aligned power-of-two group of lanes
         // of one wave, its nearest obstacle is a shuffle reduction
         const bool lanes_per_env = O > 0 && (O & (O - 1)) == 0 && TE * O <= 64;
-        for (int task = wave; task < 3; task += n_waves) {
+        for (int task = wave; task < 4; task += n_waves) {
             for (int i0 = 0; i0 < n_obst || (task == 0 && i0 == 0); i0 += 64) {
                 const int i = i0 + lane;
                 const bool live = i < n_obst;
@@ -507,35 +551,24 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
                     const size_t eo = (size_t)e * O + o;
                     double* m = a.meta + eo * 5;
                     if (task == 0) {
-                        dist = ob[OB_DIST];
+                        dist = hull_distance(ob, el, o);
                         double hd = 0.0;
                         if (o >= C) {
-                            const int q = o - C;
                             if (a.is_step) {
                                 // every edge thread has read the old position before the barrier
-                                double* pp = a.poly_pose + ((size_t)e * P + q) * 6;
+                                double* pp = a.poly_pose + ((size_t)e * P + (o - C)) * 6;
                                 pp[0] = ob[OB_X];
                                 pp[1] = ob[OB_Y];
                             }
-                            const int s0 = el * S + q * NV;
-                            const int nv = ecross[s0] >> 1;
-                            double dmin = __builtin_inf();
-                            int par = 0;
-                            for (int k = 0; k < nv; ++k) {
-                                const double dd = edist[s0 + k];
-                                dmin = dd < dmin ? dd : dmin;
-                                par ^= ecross[s0 + k] & 1;
-                            }
-                            dist = nv > 0 ? (par ? -dmin : dmin) - a.vessel_radius : __builtin_inf();
-                            ob[OB_DIST] = dist;
                             hd = ob[OB_HEADING];
                         }
-                        const double vv = rvx * rvx + rvy * rvy;
                         a.obst_dist[eo] = dist;
                         m[0] = hd;
                         m[1] = dist;
-                        m[2] = __builtin_sqrt(vv);
-                        a.risk[eo] = risk_index(mx, my, rvx, rvy, vv, dist, range, a.w_d, a.w_c, a.t_c);
+                        m[2] = __builtin_sqrt(rvx * rvx + rvy * rvy);
+                    } else if (task == 3) {
+                        a.risk[eo] = risk_index(mx, my, rvx, rvy, rvx * rvx + rvy * rvy, hull_distance(ob, el, o), range,
+                                                a.inv_range, a.w_d, a.w_c, a.t_c);
                     } else {
                         const double psi = a.state[2 * (size_t)V + e];
                         m[2 + task] = wrap_angle(atan2_det(task == 1 ? my : rvy, task == 1 ? mx : rvx) - psi);
@@ -554,10 +587,14 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
                         }
                     }
                     if (live && o == 0) env_summary(a, e, bd, bd < __builtin_inf() ? bi : -1);
+                } else if (task == 0 && live && o >= C) {
+                    // general shape: park the polygon's distance beside the
+                    // circles' for the walk below (no other task reads this slot)
+                    obst[(size_t)i * OB_COUNT + OB_DIST] = dist;
                 }
             }
             if (task == 0 && !lanes_per_env) {
-                // general shape: the wave that wrote the distances walks them per env
+                // the wave that parked the distances walks them per env
                 for (int el = lane; el < ne; el += 64) {
                     double bd = __builtin_inf();
                     int bi = -1;
@@ -663,7 +700,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
     for (int f = tid; f < ne * R; f += nthr) {
         const double t = __longlong_as_double((long long)best[f]);
         const size_t out = (size_t)e0 * R + f;
-        const float close = (float)(1.0 - t / range);
+        const float close = (float)(1.0 - div_by_const(t, range, a.inv_range));
         a.ranges[out] = t;
         a.hit[out] = (int)ids[f];
         a.perception[out] = close;
@@ -673,15 +710,13 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         if (tid < n_w) cnn_lds[tid] = w_mine;
         for (int i = tid + nthr; i < n_w; i += nthr) cnn_lds[i] = a.cnn_w[i];
         __syncthreads();
-        // one wave per scan; every output element is summed by one lane in the
-        // order k_cnn uses, so the values are the same
-        const int od = cnn_out_dim(a.cnn_kind, a.cnn_head);
+        // the tile's scans together, output elements dealt over the workgroup;
+        // each is summed by one thread in the order k_cnn uses: same values
         const int nb = cnn_buf_floats(a.cnn_kind);
         float* act = cnn_lds + ((n_w + 3) & ~3);
-        for (int s = tid >> 6; s < ne; s += nthr >> 6)
-            cnn_forward_scan<false>(reinterpret_cast<const float*>(ids) + (size_t)s * R, act + (size_t)s * 2 * nb,
-                                    act + ((size_t)s * 2 + 1) * nb, cnn_lds, a.cnn_out + (size_t)(e0 + s) * od,
-                                    a.cnn_kind, a.cnn_head, lane, 64);
+        cnn_forward<false, true>(reinterpret_cast<const float*>(ids), R, act, act + nb, 2 * nb, ne, cnn_lds,
+                                 a.cnn_out + (size_t)e0 * cnn_out_dim(a.cnn_kind, a.cnn_head), a.cnn_kind,
+                                 a.cnn_head, tid, nthr);
     }
     AUV_STAMP(9);
 }

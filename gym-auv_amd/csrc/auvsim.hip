@@ -272,6 +272,7 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.reward = bp<double>(h, AUV_BUF_REWARD);
     sa.dt = h->cfg.dt;
     sa.sensor_range = h->cfg.sensor_range;
+    sa.inv_range = 1.0 / h->cfg.sensor_range;
     sa.vessel_radius = h->cfg.vessel_radius;
     sa.w_d = h->cfg.risk[0];
     sa.w_c = h->cfg.risk[1];

@@ -1,3 +1,4 @@
+"""Diagnostic: per-phase shader-clock spans of k_sense and pair-list sizes (stamps build)."""
 import os, sys, ctypes as C
 sys.path.insert(0, '.')
 os.environ["AUVSIM_LIB"] = os.path.abspath("scratch/libauvsim_stamps.so")
@@ -18,12 +19,15 @@ lib.auv_debug_set_stamps.argtypes = [C.c_void_p]
 assert lib.auv_debug_set_stamps(C.c_void_p(stamps.data_ptr())) == 0
 sim.step_device(acts[0].data_ptr(), stream=st)
 torch.cuda.synchronize()
-s = stamps.cpu().numpy().reshape(nblk, 4, 16)[:, :, :14].astype(np.float64)
-d = np.diff(s, axis=2)          # [blk, wave, 13]
-names = ["P1 stage", "bar1", "P2 scan+obst", "bar2", "P3 offs+env", "bar3", "expand", "bar4", "sweep0", "bar5", "sweep1", "bar6", "output"]
-tot = (s[:, :, 13] - s[:, :, 0])
-print("wave lifetime mean cycles", tot.mean(), "(100 MHz ticks? memtime = shader clock)")
+raw = stamps.cpu().numpy().reshape(nblk, 4, 16)
+ncp, nep = raw[:, 0, 14], raw[:, 0, 15]
+tot = ncp + nep
+print("pairs per block: circle mean %.0f edge mean %.0f total mean %.0f p50 %d p90 %d p99 %d max %d; >1024: %.3f" % (
+    ncp.mean(), nep.mean(), tot.mean(), *np.percentile(tot, [50, 90, 99]), tot.max(), (tot > 1024).mean()))
+s = raw[:, :, :10].astype(np.float64)
+d = np.diff(s, axis=2)
+names = ["P0 init", "P1 stage", "bar1", "P2 obst", "sweep0", "bar2", "sweep1", "bar3", "output"]
 for w in range(4):
     print("wave", w, " ".join(f"{n}:{d[:, w, i].mean():7.0f}" for i, n in enumerate(names)))
 print("all  ", " ".join(f"{n}:{d[:, :, i].mean():7.0f}" for i, n in enumerate(names)))
-print("block span (first stamp to last stamp over waves)", (s[:, :, 13].max(1) - s[:, :, 0].min(1)).mean())
+print("block span", (s[:, :, 9].max(1) - s[:, :, 0].min(1)).mean())
