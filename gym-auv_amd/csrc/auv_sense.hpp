@@ -140,8 +140,11 @@ struct SenseLayout {
 
 // LDS image per tile (f64 blocks first, 16-B aligned int4 block, then words).
 //   env[TE][2] cos psi, sin psi       circ[TE*C][3] mx,my,cc       seg[TE*S][5] ax,ay,ex,ey,nt
-//   best[TE*R] u64                    obst[TE*O][8] mx,my,rvx,rvy,bearing,course,dist,-
-//   edist[TE*S] f64   meta[NP] int4   offs[NP+1]   ids[TE*R]   pairs[cap]   ecross[TE*S]   wsum[8]
+//   best[TE*R] u64     obst: 5 fields [TE*O] mx,my,rvx,rvy,dist then 3 fields [TE*P] x,y,heading
+//                      (field-major: the lanes of a wave walk the banks)
+//   edist[TE*S] f64    meta[NP] int2 {first | cnt<<16, env | obstacle<<8}
+//   ids[TE*R]   pairs[cap]   ecross[TE*S]   wsum[16]
+//   offs[NP+1] (only the overflow path, after phase 2 is over) lies over obst.
 // With a network evaluated in-kernel (cnn_kind >= 0) its weights and two
 // activation buffers per env reuse the bytes in front of best[], which are
 // dead by then; the front is padded when it is smaller than that.
@@ -159,20 +162,30 @@ __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P,
     const size_t act = sense_cnn_bytes(TE, cnn_kind);
     o = o < act ? act : o;
     L.best = o; o += (size_t)TE * R * 8;
-    L.obst = o; o += (size_t)TE * O * 8 * 8;
+    {
+        const size_t ob = ((size_t)TE * O * 5 + (size_t)TE * P * 3) * 8, of = (NP + 1) * 4;
+        L.obst = o;
+        L.offs = o;
+        o += ob > of ? ob : of;
+    }
     L.edist = o; o += (size_t)TE * S * 8;
     o = (o + 15) & ~(size_t)15;
-    L.meta = o; o += NP * 16;
-    L.offs = o; o += (NP + 1) * 4;
+    L.meta = o; o += NP * 8;
     L.ids = o; o += (size_t)TE * R * 4;
     L.pairs = o; o += (size_t)cap * 4;
     L.ecross = o; o += (size_t)TE * S * 4;
-    L.wsum = o; o += 8 * 4;
+    L.wsum = o; o += 16 * 4;
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
 
-enum ObstRec { OB_MX = 0, OB_MY, OB_RVX, OB_RVY, OB_X, OB_Y, OB_DIST, OB_HEADING, OB_COUNT = 8 };
+enum ObstRec { OB_MX = 0, OB_MY, OB_RVX, OB_RVY, OB_DIST, OB_COUNT = 5 };  // per obstacle
+enum PolyRec { PB_X = 0, PB_Y, PB_HEADING, PB_COUNT = 3 };                  // per polygon
+
+__device__ __forceinline__ int2 pack_meta(int first, int cnt, int el, int oid) {
+    return make_int2(first | (cnt << 16), el | (oid << 8));
+}
+__device__ __forceinline__ int meta_count(int2 m) { return (int)((unsigned)m.x >> 16); }
 
 // One (primitive, ray) pair of the dense list: decode, build the ray, run the
 // exact test.  `slot` = accumulator index of the ray, `oid` = obstacle id.
@@ -183,14 +196,15 @@ struct PairHit {
     unsigned long long key;
 };
 
-__device__ __forceinline__ PairHit pair_test(unsigned int pr, int R, int n_circ, double range, const int4* meta,
+__device__ __forceinline__ PairHit pair_test(unsigned int pr, int R, int n_circ, double range, const int2* meta,
                                              const double* env, const double* circ, const double* seg,
                                              const double* ray_dirs) {
     const int p = (int)(pr >> 16);
-    const int4 m = meta[p];
-    int r = m.x + (int)(pr & 0xffffu);
+    const int2 m = meta[p];
+    const int el = m.y & 0xff;
+    int r = (m.x & 0xffff) + (int)(pr & 0xffffu);
     r = r >= R ? r - R : r;
-    const double cpsi = env[m.z * 2], spsi = env[m.z * 2 + 1];
+    const double cpsi = env[el * 2], spsi = env[el * 2 + 1];
     const double cb = ray_dirs[2 * r], sb = ray_dirs[2 * r + 1];
     const double dx = cpsi * cb - spsi * sb;
     const double dy = spsi * cb + cpsi * sb;
@@ -204,8 +218,8 @@ __device__ __forceinline__ PairHit pair_test(unsigned int pr, int R, int n_circ,
     }
     PairHit h;
     h.ok = ok && t < range;
-    h.slot = m.z * R + r;
-    h.oid = (unsigned int)m.w;
+    h.slot = el * R + r;
+    h.oid = (unsigned int)m.y >> 8;
     h.key = t_key(t);
     return h;
 }
@@ -276,7 +290,7 @@ __device__ long long* g_stamps = nullptr;
 
 constexpr int kKeep = 4;  // pair-list passes whose hit keys stay in registers between the two sweeps
 
-__global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
+__global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int V = a.d.V, R = a.d.R, C = a.d.C, P = a.d.P, NV = a.d.NV, O = a.d.O;
     const int S = P * NV;
@@ -288,13 +302,16 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
     double* seg = reinterpret_cast<double*>(lds_raw + L.seg);
     unsigned long long* best = reinterpret_cast<unsigned long long*>(lds_raw + L.best);
     double* obst = reinterpret_cast<double*>(lds_raw + L.obst);
+    const int ob_n = TE * O;  // obstacle slots of the tile = stride between the fields of obst[]
+    double* pobs = obst + (size_t)OB_COUNT * ob_n;  // polygon-only fields
+    const int pb_n = TE * P;
     double* edist = reinterpret_cast<double*>(lds_raw + L.edist);
-    int4* meta = reinterpret_cast<int4*>(lds_raw + L.meta);
+    int2* meta = reinterpret_cast<int2*>(lds_raw + L.meta);
     int* offs = reinterpret_cast<int*>(lds_raw + L.offs);
     unsigned int* ids = reinterpret_cast<unsigned int*>(lds_raw + L.ids);
     unsigned int* pairs = reinterpret_cast<unsigned int*>(lds_raw + L.pairs);
     int* ecross = reinterpret_cast<int*>(lds_raw + L.ecross);
-    int* wsum = reinterpret_cast<int*>(lds_raw + L.wsum);  // [0..3] wave sums of the fallback scan, [6],[7] pair counters
+    int* wsum = reinterpret_cast<int*>(lds_raw + L.wsum);  // [0..7] wave sums of the fallback scan, [14],[15] pair counters
     const int e0 = blockIdx.x * TE;
     const int ne = min(TE, V - e0);
     const int n_circ = ne * C;
@@ -312,11 +329,11 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
 
     AUV_STAMP(0);
     // ---- phase 0: accumulators.  The pair list is filled from both ends:
-    // circle pairs grow up from slot 0 (count in wsum[6]), edge pairs grow down
-    // from slot cap (count in wsum[7]), so a wave of the sweep sees one kind.
+    // circle pairs grow up from slot 0 (count in wsum[14]), edge pairs grow down
+    // from slot cap (count in wsum[15]), so a wave of the sweep sees one kind.
     if (tid == 0) {
-        wsum[6] = 0;
-        wsum[7] = 0;
+        wsum[14] = 0;
+        wsum[15] = 0;
     }
     // heading sin/cos of the tile's vessels: requested now, filed at the end of
     // phase 1, so that the first barrier does not wait for global memory
@@ -360,12 +377,12 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         circ[i * 3 + 1] = on ? my : 0.0;
         circ[i * 3 + 2] = on ? cc : __builtin_inf();
         // obstacle record for phase 2
-        double* ob = obst + ((size_t)el * O + j) * OB_COUNT;
-        ob[OB_MX] = mx;
-        ob[OB_MY] = my;
-        ob[OB_RVX] = vx - er[ER_VOX];
-        ob[OB_RVY] = vy - er[ER_VOY];
-        ob[OB_DIST] = on ? (__builtin_sqrt(mm) - rad) - a.vessel_radius : __builtin_inf();
+        double* ob = obst + (el * O + j);
+        ob[OB_MX * ob_n] = mx;
+        ob[OB_MY * ob_n] = my;
+        ob[OB_RVX * ob_n] = vx - er[ER_VOX];
+        ob[OB_RVY * ob_n] = vy - er[ER_VOY];
+        ob[OB_DIST * ob_n] = on ? (__builtin_sqrt(mm) - rad) - a.vessel_radius : __builtin_inf();
         // candidate rays
         const float fr = (float)rad, fmx = (float)mx, fmy = (float)my;
         const float fmm = fmx * fmx + fmy * fmy;
@@ -381,9 +398,9 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
             const float hw = fast_atan2f(fr, sqrtf(fmm - fr * fr)) * inv_delta;
             iv = make_interval(xc - hw, xc + hw, R, margin);
         }
-        meta[i] = make_int4(iv.x, iv.y, el, j);
+        meta[i] = pack_meta(iv.x, iv.y, el, j);
         if (iv.y > 0) {
-            const int base = atomicAdd(&wsum[6], iv.y);
+            const int base = atomicAdd(&wsum[14], iv.y);
             const int room = min(iv.y, cap - base);  // writes stay inside the list even when it overflows
             for (int k = 0; k < room; ++k) pairs[base + k] = ((unsigned int)i << 16) | (unsigned int)k;
         }
@@ -413,14 +430,15 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         if (k == 0) {
             // one edge thread per polygon files its obstacle record for phase 2
             const double* er = a.envrec + (size_t)e * ER_COUNT;
-            double* ob = obst + ((size_t)el * O + C + q) * OB_COUNT;
-            ob[OB_MX] = X - px;
-            ob[OB_MY] = Y - py;
-            ob[OB_RVX] = pvx - er[ER_VOX];
-            ob[OB_RVY] = pvy - er[ER_VOY];
-            ob[OB_X] = X;  // advanced position, written back in phase 2
-            ob[OB_Y] = Y;
-            ob[OB_HEADING] = a.poly_heading[ep];
+            double* ob = obst + (el * O + C + q);
+            ob[OB_MX * ob_n] = X - px;
+            ob[OB_MY * ob_n] = Y - py;
+            ob[OB_RVX * ob_n] = pvx - er[ER_VOX];
+            ob[OB_RVY * ob_n] = pvy - er[ER_VOY];
+            double* pb = pobs + (el * P + q);
+            pb[PB_X * pb_n] = X;  // advanced position, written back in phase 2
+            pb[PB_Y * pb_n] = Y;
+            pb[PB_HEADING * pb_n] = a.poly_heading[ep];
         }
         double ax = 0.0, ay = 0.0, ex = 0.0, ey = 0.0, nt = 0.0, dd = __builtin_inf();
         int cross = 0;
@@ -483,9 +501,9 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         sg[4] = nt;
         edist[i] = dd;
         ecross[i] = k == 0 ? (cross | (nv << 1)) : cross;  // edge 0 also carries the vertex count
-        meta[n_circ + i] = make_int4(iv.x, iv.y, el, C + q);
+        meta[n_circ + i] = pack_meta(iv.x, iv.y, el, C + q);
         if (iv.y > 0) {
-            const int used = atomicAdd(&wsum[7], iv.y);
+            const int used = atomicAdd(&wsum[15], iv.y);
             const int top = cap - used;  // exclusive upper slot of this primitive's run
             const int room = min(iv.y, top);
             for (int kk = 0; kk < room; ++kk)
@@ -499,7 +517,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
     AUV_STAMP(2);
     __syncthreads();
     AUV_STAMP(3);
-    const int n_cp = wsum[6], n_ep = wsum[7];
+    const int n_cp = wsum[14], n_ep = wsum[15];
 #ifdef AUV_PHASE_STAMPS
     if (g_stamps && tid == 0) {
         g_stamps[(size_t)blockIdx.x * 64 + 14] = n_cp;
@@ -521,7 +539,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         // signed hull distance less the vessel radius; polygons: nearest edge
         // (sqrt of the smallest squared distance), sign from the crossing parity
         auto hull_distance = [&](const double* ob, int el, int o) -> double {
-            if (o < C) return ob[OB_DIST];
+            if (o < C) return ob[OB_DIST * ob_n];
             const int s0 = el * S + (o - C) * NV;
             const int nv = ecross[s0] >> 1;
             double dmin2 = __builtin_inf();
@@ -546,21 +564,22 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
                 const int e = e0 + el;
                 double dist = __builtin_inf();
                 if (live) {
-                    double* ob = obst + (size_t)i * OB_COUNT;
-                    const double mx = ob[OB_MX], my = ob[OB_MY], rvx = ob[OB_RVX], rvy = ob[OB_RVY];
+                    double* ob = obst + i;
+                    const double mx = ob[OB_MX * ob_n], my = ob[OB_MY * ob_n], rvx = ob[OB_RVX * ob_n], rvy = ob[OB_RVY * ob_n];
                     const size_t eo = (size_t)e * O + o;
                     double* m = a.meta + eo * 5;
                     if (task == 0) {
                         dist = hull_distance(ob, el, o);
                         double hd = 0.0;
                         if (o >= C) {
+                            const double* pb = pobs + (el * P + (o - C));
                             if (a.is_step) {
                                 // every edge thread has read the old position before the barrier
                                 double* pp = a.poly_pose + ((size_t)e * P + (o - C)) * 6;
-                                pp[0] = ob[OB_X];
-                                pp[1] = ob[OB_Y];
+                                pp[0] = pb[PB_X * pb_n];
+                                pp[1] = pb[PB_Y * pb_n];
                             }
-                            hd = ob[OB_HEADING];
+                            hd = pb[PB_HEADING * pb_n];
                         }
                         a.obst_dist[eo] = dist;
                         m[0] = hd;
@@ -590,7 +609,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
                 } else if (task == 0 && live && o >= C) {
                     // general shape: park the polygon's distance beside the
                     // circles' for the walk below (no other task reads this slot)
-                    obst[(size_t)i * OB_COUNT + OB_DIST] = dist;
+                    obst[OB_DIST * ob_n + i] = dist;
                 }
             }
             if (task == 0 && !lanes_per_env) {
@@ -599,7 +618,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
                     double bd = __builtin_inf();
                     int bi = -1;
                     for (int o = 0; o < O; ++o) {
-                        const double d = obst[((size_t)el * O + o) * OB_COUNT + OB_DIST];
+                        const double d = obst[OB_DIST * ob_n + el * O + o];
                         if (d < bd) {
                             bd = d;
                             bi = o;
@@ -652,7 +671,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         const int chunk = (NP + nthr - 1) / nthr;
         const int p_lo = min(tid * chunk, NP), p_hi = min(p_lo + chunk, NP);
         int mine = 0;
-        for (int p = p_lo; p < p_hi; ++p) mine += meta[p].y;
+        for (int p = p_lo; p < p_hi; ++p) mine += meta_count(meta[p]);
         int incl = mine;
         for (int d = 1; d < 64; d <<= 1) {
             const int up = __shfl_up(incl, d, 64);
@@ -665,7 +684,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
         int run = base + incl - mine;
         for (int p = p_lo; p < p_hi; ++p) {
             offs[p] = run;
-            run += meta[p].y;
+            run += meta_count(meta[p]);
         }
         __syncthreads();
         const int n_rounds = (total + cap - 1) / cap;
@@ -675,7 +694,7 @@ __global__ __launch_bounds__(256) void k_sense(SenseArgs a) {
                 const int n_pairs = min(cap, total - w0);
                 for (int p = tid; p < NP; p += nthr) {
                     const int o = offs[p];
-                    const int lo = max(o, w0), hi = min(o + meta[p].y, w0 + cap);
+                    const int lo = max(o, w0), hi = min(o + meta_count(meta[p]), w0 + cap);
                     for (int w = lo; w < hi; ++w) pairs[w - w0] = ((unsigned int)p << 16) | (unsigned int)(w - o);
                 }
                 __syncthreads();

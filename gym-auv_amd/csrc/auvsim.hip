@@ -770,8 +770,8 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
             h->lidar_mode = value;
             return AUV_OK;
         case AUV_OPT_SENSE_BLOCK:
-            if (value != 64 && value != 128 && value != 256)
-                return fail(h, AUV_ERR_ARG, "auv_set_option: k_sense workgroup size must be 64, 128 or 256");
+            if (value != 64 && value != 128 && value != 256 && value != 512)
+                return fail(h, AUV_ERR_ARG, "auv_set_option: k_sense workgroup size must be 64, 128, 256 or 512");
             h->sense_block = value;
             return AUV_OK;
         case AUV_OPT_RASTER_TILE:
