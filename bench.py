@@ -48,23 +48,60 @@ def sense_bytes_per_env(R, C, P, NV):
 VESSEL_BYTES_PER_ENV = 48 + 48 + 16 + 48 + 64 + 16 + 8 + 8 + 24 + 2 + 8  # state rw, action, path, record, own, along rw, nav, flags, t_step
 
 
-def cpu_baseline(name, n_envs, steps):
-    """The numpy oracle on a bounded sample of the same workload, one core."""
+def _cpu_worker(job):
+    """One process of the CPU baseline: `n_envs` envs of the workload (its own
+    seed offset) stepped `steps` times by the numpy oracle.  Returns (stepping
+    seconds, wall-clock start, wall-clock end)."""
+    name, n_envs, steps, rank = job
     from gym_auv_amd import scenarios
     from tests.helpers import make_oracle
 
-    cfg, scene = scenarios.make_workload(name, n_envs=n_envs)
+    cfg, scene = scenarios.make_workload(name, n_envs=n_envs, rank=rank)
     env = make_oracle(cfg, scene)
     env.reset(scene["init_state"])
-    acts = scenarios.random_actions(n_envs, steps, seed=7)
+    acts = scenarios.random_actions(n_envs, steps, seed=7 + rank)
+    w0 = time.time()
     t0 = time.perf_counter()
     for k in range(steps):
         env.step(acts[k])
-    dt = time.perf_counter() - t0
-    return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n_envs} envs x {steps} steps of {name} (numpy fp64 oracle; substitute for "
-                      f"the absent reference env), {dt:.1f} s",
-            "rays_per_s": n_envs * steps * cfg["n_rays"] / dt}
+    return time.perf_counter() - t0, w0, time.time()
+
+
+def cpu_baseline(name, n_envs, steps, procs):
+    """The numpy oracle on a bounded sample of the same workload: `procs`
+    processes (spawned, so none inherits the GPU context), each one core, each
+    stepping its own `n_envs` envs; the rate is all their env-steps over the span
+    from the first start to the last end.  The one-core rate is process 0's."""
+    import multiprocessing as mp
+
+    from gym_auv_amd import scenarios
+
+    R = scenarios.WORKLOADS[name]["R"]
+    jobs = [(name, n_envs, steps, r) for r in range(procs)]
+    if procs == 1:
+        res = [_cpu_worker(jobs[0])]
+    else:
+        with mp.get_context("spawn").Pool(procs) as pool:
+            res = pool.map(_cpu_worker, jobs, chunksize=1)
+    span = max(r[2] for r in res) - min(r[1] for r in res)
+    total = n_envs * steps * procs
+    return {"value": total / span, "unit": "env-steps/s", "cores": procs, "kind": "port",
+            "sample": f"{procs} processes x {n_envs} envs x {steps} steps of {name} (numpy fp64 oracle, one core "
+                      f"each; substitute for the absent reference env), {span:.1f} s",
+            "rays_per_s": total * R / span,
+            "one_core": {"value": n_envs * steps / res[0][0], "unit": "env-steps/s"}}
+
+
+def measured_traffic(key, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary for this
+    exact workload, or None (the counters are collected by separate rocprofv3
+    passes, not inside this run)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            e = json.load(f)[key][kernel]
+        return (2.0 * e["fetch_kib"] + e["write_kib"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -84,6 +121,8 @@ def main():
     ap.add_argument("--gather-scans", action="store_true",
                     help="also gather the final scans of every rank on rank 0 once per rollout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-procs", type=int, default=0,
+                    help="processes of the CPU baseline, one core each (0 = the CPUs this process may use, at most 16)")
     ap.add_argument("--cpu-envs", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=60)
     args = ap.parse_args()
@@ -246,20 +285,23 @@ def main():
             out["roofline_cnn"] = {"kernel": "k_cnn", "bound": "hbm", "achieved": cb / cnn_ms / 1e6,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cb / cnn_ms / 1e6 / HBM_PEAK_GBS,
                                    "traffic": None, "avg_launch_ms": cnn_ms}
+        tkey = f"{args.workload}/{V}/" + (f"{args.cnn}-attached" if cnn_dim else
+                                           f"{args.cnn}-separate" if net is not None else "none")
         if fused:
             nbytes = float(sense_bytes_per_env(R, C, P, NV) + 4 * cnn_dim) * V
             gbs = nbytes / sense_s / 1e9
             out["roofline"] = {
                 "kernel": "k_sense", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": nbytes,
+                "frac": gbs / HBM_PEAK_GBS, "traffic": measured_traffic(tkey, "k_sense"),
+                "bytes_per_launch": nbytes,
                 "avg_launch_ms": sense_s * 1e3,
                 "note": "rasterised LiDAR + encounter + obstacle advance in one pass over the scene; "
                         "algorithmic bytes = scene + vessel record in, positions + all outputs out"}
             vb = float(VESSEL_BYTES_PER_ENV) * V
             out["roofline_vessel"] = {
                 "kernel": "k_vessel", "bound": "hbm", "achieved": vb / vessel_s / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": vb / vessel_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                "avg_launch_ms": vessel_s * 1e3}
+                "unit": "GB/s", "frac": vb / vessel_s / 1e9 / HBM_PEAK_GBS,
+                "traffic": measured_traffic(tkey, "k_vessel"), "avg_launch_ms": vessel_s * 1e3}
             out["allpairs_equivalent"] = {
                 "bound": "valu", "achieved": flops / sense_s / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": flops / sense_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
@@ -273,8 +315,9 @@ def main():
                 "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
                 "flops_per_launch": flops, "avg_launch_ms": sense_s * 1e3,
                 "note": "fp64 vector (non-MFMA) roofline; (16*circles + 18*edges) flop per ray"}
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_envs, args.cpu_steps)
+        if not args.no_cpu_baseline and world == 1:
+            procs = args.cpu_procs or max(1, min(16, len(os.sched_getaffinity(0))))
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_envs, args.cpu_steps, procs)
         print(json.dumps(out), flush=True)
     sim.close()
     if world > 1:
