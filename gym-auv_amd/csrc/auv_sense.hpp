@@ -26,12 +26,21 @@
 namespace auv {
 
 // per-vessel record handed from k_vessel to k_sense, f64 [V,8]
-enum EnvRec { ER_COS = 0, ER_SIN, ER_VOX, ER_VOY, ER_REWARD, ER_COUNT = 8 };
+enum EnvRec { ER_COS = 0, ER_SIN, ER_VOX, ER_VOY, ER_REWARD, ER_RESET, ER_COUNT = 8 };
 
 struct VesselArgs {
     int V;
     int do_step;  // 1: integrate and count the step; 0: state was just (re)set
+    int auto_reset;  // 1: an env whose done flag is set restarts from `init` instead of integrating
     int max_steps;
+    const uint8_t* done;  // flags of the previous sensing pass
+    const double* init;   // [6,V] initial states of the last reset call
+    // obstacle positions of a restarting env go back to the uploaded ones
+    int C, P;
+    double* circles;           // [V,C,5]
+    const double* circles0;
+    double* poly_pose;         // [V,P,6]
+    const double* poly_pose0;
     double* state;         // [6,V]
     const double* action;  // [2,V]
     int32_t* t_step;
@@ -52,10 +61,26 @@ __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
     if (i >= V) return;
     Vec6 s = load_state(a.state, V, i);
     int t = a.t_step[i];
+    const bool restart = a.do_step && a.auto_reset && a.done[i] != 0;
     if (a.do_step) {
-        s = rkf45_step(s, a.action[i], a.action[(size_t)V + i], a.dt, a.thrust_max, a.moment_max, a.mp);
+        if (restart) {
+            s = load_state(a.init, V, i);
+            t = 0;
+            for (int j = 0; j < a.C; ++j) {
+                const size_t o = ((size_t)i * a.C + j) * 5;
+                a.circles[o] = a.circles0[o];
+                a.circles[o + 1] = a.circles0[o + 1];
+            }
+            for (int q = 0; q < a.P; ++q) {
+                const size_t o = ((size_t)i * a.P + q) * 6;
+                a.poly_pose[o] = a.poly_pose0[o];
+                a.poly_pose[o + 1] = a.poly_pose0[o + 1];
+            }
+        } else {
+            s = rkf45_step(s, a.action[i], a.action[(size_t)V + i], a.dt, a.thrust_max, a.moment_max, a.mp);
+            t = t + 1;
+        }
         store_state(a.state, V, i, s);
-        t = t + 1;
         a.t_step[i] = t;
     }
     const SinCos sc = sincos_det(s.psi);
@@ -85,7 +110,7 @@ __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
     a.reached_goal[i] = ((len - al) <= a.goal_radius) ? 1 : 0;
     a.truncated[i] = (t >= a.max_steps) ? 1 : 0;
     double rew = 0.0;
-    if (a.do_step) {
+    if (a.do_step && !restart) {
         rew = a.rw_progress * (al - al_prev);
         rew = rew - a.rw_cte * __builtin_fabs(cte);
     }
@@ -95,6 +120,7 @@ __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
     er[ER_VOX] = vox;
     er[ER_VOY] = voy;
     er[ER_REWARD] = rew;
+    er[ER_RESET] = restart ? 1.0 : 0.0;
 }
 
 struct SenseArgs {
@@ -267,9 +293,11 @@ __device__ __forceinline__ void env_summary(const SenseArgs& a, int e, double bd
     a.collision[e] = coll;
     double rew = 0.0;
     if (a.is_step) {
-        rew = a.envrec[(size_t)e * ER_COUNT + ER_REWARD];
+        const double* er = a.envrec + (size_t)e * ER_COUNT;
+        rew = er[ER_REWARD];
         rew = rew - (coll ? a.rw_collision : 0.0);
         rew = rew + (goal ? a.rw_goal : 0.0);
+        if (er[ER_RESET] != 0.0) rew = 0.0;  // first observation of a new episode
     }
     a.reward[e] = rew;
     a.done[e] = coll | goal | a.truncated[e];
@@ -360,14 +388,14 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
         double* c = a.circles + ((size_t)e0 * C + i) * 5;
         double cx = c[0], cy = c[1];
         const double rad = c[2], vx = c[3], vy = c[4];
-        if (a.is_step) {
+        const double* er = a.envrec + (size_t)e * ER_COUNT;
+        if (a.is_step && er[ER_RESET] == 0.0) {  // a restarted env's obstacles were just put back by k_vessel
             cx = cx + vx * a.dt;
             cy = cy + vy * a.dt;
             c[0] = cx;
             c[1] = cy;
         }
         const double psi = a.state[2 * (size_t)V + e];
-        const double* er = a.envrec + (size_t)e * ER_COUNT;
         const double mx = cx - a.state[e];
         const double my = cy - a.state[(size_t)V + e];
         const double mm = mx * mx + my * my;
@@ -421,7 +449,7 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
         const double v1x = vb[2 * k1c], v1y = vb[2 * k1c + 1], v0x = vb[0], v0y = vb[1];
         double X = p[0], Y = p[1];
         const double ch = p[2], sh = p[3], pvx = p[4], pvy = p[5];
-        if (a.is_step) {
+        if (a.is_step && a.envrec[(size_t)e * ER_COUNT + ER_RESET] == 0.0) {
             X = X + pvx * a.dt;
             Y = Y + pvy * a.dt;
         }

@@ -71,6 +71,7 @@ struct auv_sim {
     int lidar_mode = AUV_LIDAR_RASTER;
     int raster_te = 1, raster_cap = 2048, sense_block = 256;
     int raster_want = 0;  // envs per workgroup asked for (0 = automatic)
+    int auto_reset = 0;   // done envs restart inside the next step
     size_t raster_lds = 0;
     // attached LiDAR-CNN: a private copy of its weights, evaluated with every sensing pass
     float* cnn_w = nullptr;
@@ -219,6 +220,15 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     VesselArgs va;
     va.V = d.V;
     va.do_step = do_step;
+    va.auto_reset = h->auto_reset;
+    va.done = bp<uint8_t>(h, AUV_BUF_DONE);
+    va.init = h->init_stage;
+    va.C = d.C;
+    va.P = d.P;
+    va.circles = bp<double>(h, AUV_BUF_CIRCLES);
+    va.circles0 = h->circles0;
+    va.poly_pose = bp<double>(h, AUV_BUF_POLY_POSE);
+    va.poly_pose0 = h->poly_pose0;
     va.max_steps = h->cfg.max_steps;
     va.state = bp<double>(h, AUV_BUF_STATE);
     va.action = action;
@@ -764,6 +774,8 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
         case AUV_OPT_LIDAR_MODE:
             if (value != AUV_LIDAR_RASTER && value != AUV_LIDAR_ALL_PAIRS)
                 return fail(h, AUV_ERR_ARG, "auv_set_option: unknown LiDAR mode %d", value);
+            if (value == AUV_LIDAR_ALL_PAIRS && h->auto_reset)
+                return fail(h, AUV_ERR_ARG, "auv_set_option: the all-pairs path has no in-step restart; clear AUV_OPT_AUTO_RESET first");
             if (value == AUV_LIDAR_RASTER && h->raster_lds > kLdsMax)
                 return fail(h, AUV_ERR_ARG, "auv_set_option: rasterising LiDAR needs %zu B of LDS per env (limit 163840)",
                             h->raster_lds);
@@ -773,6 +785,12 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
             if (value != 64 && value != 128 && value != 256 && value != 512)
                 return fail(h, AUV_ERR_ARG, "auv_set_option: k_sense workgroup size must be 64, 128, 256 or 512");
             h->sense_block = value;
+            return AUV_OK;
+        case AUV_OPT_AUTO_RESET:
+            if (value != 0 && value != 1) return fail(h, AUV_ERR_ARG, "auv_set_option: AUV_OPT_AUTO_RESET takes 0 or 1");
+            if (value && h->lidar_mode != AUV_LIDAR_RASTER)
+                return fail(h, AUV_ERR_ARG, "auv_set_option: in-step restart needs the rasterising path");
+            h->auto_reset = value;
             return AUV_OK;
         case AUV_OPT_RASTER_TILE:
             if (value < 0 || value > 64)

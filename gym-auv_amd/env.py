@@ -32,8 +32,21 @@ class DictSpace:
 
 
 class VecAuvEnv:
-    def __init__(self, cfg: dict, scene: dict, device: int = 0, auto_reset: bool = True):
+    """auto_reset:
+      True / "host"  a done env is reset right after the step that ended it, through
+                     a host-side mask (one device -> host copy of the flags per step);
+                     the step returns the fresh observation, `info["terminal_mask"]`
+                     marks the envs that ended;
+      "device"       no host round trip: a done env restarts INSIDE the next step
+                     (its action is ignored, reward 0); the step that ends an episode
+                     returns the terminal observation with done = True;
+      False          done envs keep stepping until `reset()`.
+    """
+
+    def __init__(self, cfg: dict, scene: dict, device: int = 0, auto_reset=True):
         import torch
+
+        from . import _lib
 
         self._torch = torch
         self.cfg = cfg
@@ -42,7 +55,11 @@ class VecAuvEnv:
         self.device = torch.device("cuda", device)
         self.sim = AuvSim(cfg, device=device)
         self.sim.set_scene(scene)
-        self.auto_reset = auto_reset
+        self.auto_reset = "host" if auto_reset is True else auto_reset
+        if self.auto_reset not in ("host", "device", False):
+            raise ValueError("auto_reset must be True, 'host', 'device' or False")
+        if self.auto_reset == "device":
+            self.sim.set_option(_lib.OPT_AUTO_RESET, 1)
         R = int(cfg["n_rays"])
         self.observation_space = DictSpace({
             "perception": Box(0.0, 1.0, (1, R)),
@@ -80,7 +97,7 @@ class VecAuvEnv:
             self._action.copy_(actions.to(self.device).t())
             self.sim.step_device(None, stream=st)
         info = {}
-        if self.auto_reset:
+        if self.auto_reset == "host":
             done_host = self._done.cpu().numpy().astype(bool)
             if done_host.any():
                 info["terminal_mask"] = done_host

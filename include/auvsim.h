@@ -106,7 +106,12 @@ typedef enum auv_buffer {
 typedef enum auv_option {
     AUV_OPT_LIDAR_MODE = 0,   /* AUV_LIDAR_RASTER (default) | AUV_LIDAR_ALL_PAIRS */
     AUV_OPT_RASTER_TILE = 1,  /* envs per workgroup of the rasterising kernel; 0 = auto */
-    AUV_OPT_SENSE_BLOCK = 2   /* threads per k_sense workgroup: 64, 128 or 256 */
+    AUV_OPT_SENSE_BLOCK = 2,  /* threads per k_sense workgroup: 64, 128, 256 or 512 */
+    AUV_OPT_AUTO_RESET = 3    /* 1: an env whose done flag is set restarts INSIDE the next auv_step, with no
+                               * host round trip: its action is ignored, the vessel takes the initial state
+                               * of the most recent auv_reset call, its step counter is cleared, its
+                               * obstacles return to their uploaded poses, its reward is 0 and its flags
+                               * are those of the fresh state (rasterising path only; default 0) */
 } auv_option;
 #define AUV_LIDAR_RASTER 0
 #define AUV_LIDAR_ALL_PAIRS 1

@@ -494,6 +494,9 @@ class OracleEnv:
         self.t_step = np.zeros(V, dtype=np.int32)
         self.path = np.zeros((V, 6))
         self.path[:, 3] = 1.0
+        # in-step restart: an env whose done flag is set is reset by the next
+        # step() instead of being integrated (reward 0, action ignored)
+        self.auto_reset = False
 
     def set_scene(self, circles, poly_pose, poly_verts, poly_nv, poly_heading=None):
         self.circles = np.array(circles, dtype=np.float64, copy=True)
@@ -511,6 +514,7 @@ class OracleEnv:
 
     def reset(self, init_state, mask=None):
         init_state = np.asarray(init_state, dtype=np.float64)
+        self.init0 = init_state.copy()
         # a reset also puts the env's obstacles back where they were uploaded
         if mask is None:
             self.state = init_state.copy()
@@ -558,10 +562,17 @@ class OracleEnv:
     def step(self, action):
         cfg = self.cfg
         action = np.asarray(action, dtype=np.float64)
+        restart = self.done.astype(bool) if self.auto_reset else np.zeros(self.state.shape[1], dtype=bool)
         advance_obstacles(self.circles, self.poly_pose, cfg["dt"])
         self.state = step_dynamics(self.state, action, cfg)
         self.t_step = self.t_step + 1
+        if restart.any():
+            self.state[:, restart] = self.init0[:, restart]
+            self.t_step[restart] = 0
+            self.circles[restart, :, :2] = self.circles0[restart, :, :2]
+            self.poly_pose[restart, :, :2] = self.poly_pose0[restart, :, :2]
         self.sense(is_step=True)
+        self.reward[restart] = 0.0
 
 
 # ----------------------------------------------------------------------------

@@ -97,6 +97,42 @@ def test_collisions_goal_and_truncation_flags():
     sim.close()
 
 
+def test_in_step_restart_matches_oracle():
+    """AUV_OPT_AUTO_RESET: an env whose done flag is set restarts inside the next
+    step (initial state, step counter 0, obstacles at their uploaded poses,
+    reward 0), with no host round trip.  Episodes end here by collision, goal
+    and truncation, repeatedly, and every buffer must follow the oracle's bits;
+    the batch does not fill its last tile."""
+    from gym_auv_amd import _lib
+
+    V = 131
+    cfg = params.make_config(V, 6, 6, 5, max_steps=30, goal_radius=5.0)
+    scene = scenarios.make_scene(V, 6, 6, 5, seed=25, extent=60.0, width=(8.0, 25.0))
+    scene["path"][:, 5] = 12.0
+    sim = make_sim(cfg, scene)
+    sim.set_option(_lib.OPT_AUTO_RESET, 1)
+    env = make_oracle(cfg, scene)
+    env.auto_reset = True
+    sim.reset(scene["init_state"])
+    env.reset(scene["init_state"])
+    acts = scenarios.random_actions(V, 100, seed=24)
+    acts[:, 0] = 1.0
+    acts[:, 1] *= 0.1
+    restarts = 0
+    seen = np.zeros(3, dtype=bool)
+    for k in range(100):
+        restarts += int(env.done.sum())
+        sim.step_host(acts[k])
+        env.step(acts[k])
+        assert_all_equal(sim, env, f"after step {k + 1}")
+        seen |= [env.collision.any(), env.reached_goal.any(), env.truncated.any()]
+    assert restarts > V and seen.all(), (restarts, seen)
+    # the cross-check path has no in-step restart and says so
+    with pytest.raises(Exception, match="all-pairs"):
+        sim.set_option(_lib.OPT_LIDAR_MODE, _lib.LIDAR_ALL_PAIRS)
+    sim.close()
+
+
 def test_masked_reset_matches_oracle():
     cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=97)
     sim = make_sim(cfg, scene)
@@ -248,4 +284,14 @@ def test_vec_env_gym_contract():
     assert rew.shape == (64,) and done.shape == (64,) and done.dtype == torch.bool
     obs, rew, done, info = venv.step(a.cpu().numpy())
     assert torch.isfinite(obs["perception"]).all()
+    venv.close()
+    # restart on the device: the step after a done flag yields reward 0 and a cleared step counter
+    cfg2 = dict(cfg, max_steps=3)
+    venv = VecAuvEnv(cfg2, scene, auto_reset="device")
+    venv.reset()
+    for k in range(3):
+        obs, rew, done, info = venv.step(a)
+    assert done.all() and "terminal_mask" not in info        # truncated after 3 steps
+    obs, rew, done, info = venv.step(a)
+    assert (rew == 0).all() and (venv.sim.read("t_step") == 0).all()
     venv.close()
