@@ -22,7 +22,7 @@ F64, F32, I32, U8, I64 = 0, 1, 2, 3, 4
 (BUF_STATE, BUF_ACTION, BUF_RANGES, BUF_HIT, BUF_PERCEPTION, BUF_NAVIGATION,
  BUF_OBST_DIST, BUF_RISK, BUF_META, BUF_OWN, BUF_COLLISION, BUF_REACHED_GOAL,
  BUF_TRUNCATED, BUF_DONE, BUF_MIN_DIST, BUF_MIN_IDX, BUF_ALONG, BUF_T_STEP,
- BUF_CIRCLES, BUF_POLY_POSE, BUF_REWARD, BUF_CNN_OUT, BUF_COUNT) = range(23)
+ BUF_CIRCLES, BUF_POLY_POSE, BUF_REWARD, BUF_CNN_OUT, BUF_EPISODE, BUF_COUNT) = range(24)
 
 BUFFER_NAMES = {
     "state": BUF_STATE, "action": BUF_ACTION, "ranges": BUF_RANGES, "hit": BUF_HIT,
@@ -31,11 +31,11 @@ BUFFER_NAMES = {
     "reached_goal": BUF_REACHED_GOAL, "truncated": BUF_TRUNCATED, "done": BUF_DONE,
     "min_dist": BUF_MIN_DIST, "min_idx": BUF_MIN_IDX, "along": BUF_ALONG,
     "t_step": BUF_T_STEP, "circles": BUF_CIRCLES, "poly_pose": BUF_POLY_POSE,
-    "reward": BUF_REWARD, "cnn_out": BUF_CNN_OUT,
+    "reward": BUF_REWARD, "cnn_out": BUF_CNN_OUT, "episode": BUF_EPISODE,
 }
 
 # auv_option
-OPT_LIDAR_MODE, OPT_RASTER_TILE, OPT_SENSE_BLOCK, OPT_AUTO_RESET = 0, 1, 2, 3
+OPT_LIDAR_MODE, OPT_RASTER_TILE, OPT_SENSE_BLOCK, OPT_AUTO_RESET, OPT_REGENERATE = 0, 1, 2, 3, 4
 LIDAR_RASTER, LIDAR_ALL_PAIRS = 0, 1
 
 # CNN consumers
@@ -49,7 +49,7 @@ EXPORTS = (
     "auv_get_buffer", "auv_read_buffer", "auv_dlpack", "auv_sync", "auv_set_option",
     "auv_profile_enable", "auv_cnn_n_weights", "auv_cnn_out_dim", "auv_cnn_create", "auv_cnn_destroy",
     "auv_cnn_forward", "auv_cnn_last_error", "auv_format_rows",
-    "auv_profile_read", "auv_attach_cnn",
+    "auv_profile_read", "auv_attach_cnn", "auv_generate_scene",
 )
 
 
@@ -63,6 +63,11 @@ class AuvConfig(C.Structure):
         ("goal_radius", C.c_double), ("risk", C.c_double * 3), ("reward", C.c_double * 4),
         ("model", C.c_double * N_MODEL),
     ]
+
+
+class AuvSceneParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("extent", "r_lo", "r_hi", "w_lo", "w_hi", "s_lo", "s_hi", "clearance",
+                                          "path_length")]
 
 
 class AuvError(RuntimeError):
@@ -142,6 +147,8 @@ def load():
     lib.auv_cnn_forward.argtypes = [vp, vp, i64, i32, vp, vp]
     lib.auv_cnn_last_error.restype = C.c_char_p
     lib.auv_cnn_last_error.argtypes = [vp]
+    lib.auv_generate_scene.restype = C.c_int
+    lib.auv_generate_scene.argtypes = [vp, C.c_uint64, C.POINTER(AuvSceneParams), vp]
     lib.auv_attach_cnn.restype = C.c_int
     lib.auv_attach_cnn.argtypes = [vp, vp, i32]
     _lib = lib

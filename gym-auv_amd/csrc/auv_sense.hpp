@@ -35,7 +35,9 @@ struct VesselArgs {
     int max_steps;
     const uint8_t* done;  // flags of the previous sensing pass
     const double* init;   // [6,V] initial states of the last reset call
-    // obstacle positions of a restarting env go back to the uploaded ones
+    // the obstacles of a restarting env go back to their initial records
+    // (uploaded, or just regenerated for the new episode); episode[] counts restarts
+    int32_t* episode;
     int C, P;
     double* circles;           // [V,C,5]
     const double* circles0;
@@ -66,16 +68,10 @@ __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
         if (restart) {
             s = load_state(a.init, V, i);
             t = 0;
-            for (int j = 0; j < a.C; ++j) {
-                const size_t o = ((size_t)i * a.C + j) * 5;
-                a.circles[o] = a.circles0[o];
-                a.circles[o + 1] = a.circles0[o + 1];
-            }
-            for (int q = 0; q < a.P; ++q) {
-                const size_t o = ((size_t)i * a.P + q) * 6;
-                a.poly_pose[o] = a.poly_pose0[o];
-                a.poly_pose[o + 1] = a.poly_pose0[o + 1];
-            }
+            a.episode[i] = a.episode[i] + 1;
+            for (int k = 0; k < a.C * 5; ++k) a.circles[(size_t)i * a.C * 5 + k] = a.circles0[(size_t)i * a.C * 5 + k];
+            for (int k = 0; k < a.P * 6; ++k)
+                a.poly_pose[(size_t)i * a.P * 6 + k] = a.poly_pose0[(size_t)i * a.P * 6 + k];
         } else {
             s = rkf45_step(s, a.action[i], a.action[(size_t)V + i], a.dt, a.thrust_max, a.moment_max, a.mp);
             t = t + 1;

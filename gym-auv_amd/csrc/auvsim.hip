@@ -17,6 +17,7 @@
 #include "auv_lidar_raster.hpp"
 #include "auv_sense.hpp"
 #include "auv_cnn.hpp"
+#include "auv_scenegen.hpp"
 
 using namespace auv;
 
@@ -72,6 +73,10 @@ struct auv_sim {
     int raster_te = 1, raster_cap = 2048, sense_block = 256;
     int raster_want = 0;  // envs per workgroup asked for (0 = automatic)
     int auto_reset = 0;   // done envs restart inside the next step
+    int regenerate = 0;   // ... with a newly generated scene
+    bool have_generator = false, have_init = false;
+    uint64_t gen_seed = 0;
+    auv_scene_params gen_params;
     size_t raster_lds = 0;
     // attached LiDAR-CNN: a private copy of its weights, evaluated with every sensing pass
     float* cnn_w = nullptr;
@@ -198,6 +203,37 @@ void choose_geometry(auv_sim* h) {
     h->enc_lds = (size_t)eb * O * sizeof(double);
 }
 
+// scenario generator: every env (only_done == nullptr) or the envs about to restart
+int launch_scenegen(auv_sim* h, hipStream_t st, const uint8_t* only_done) {
+    const Dims& d = h->d;
+    SceneGenArgs ga;
+    ga.d = d;
+    ga.seed = h->gen_seed;
+    ga.only_done = only_done;
+    ga.episode = bp<int32_t>(h, AUV_BUF_EPISODE);
+    ga.circles0 = h->circles0;
+    ga.poly_pose0 = h->poly_pose0;
+    ga.poly_verts = h->poly_verts;
+    ga.poly_nv = h->poly_nv;
+    ga.poly_heading = h->poly_heading;
+    ga.path = h->path;
+    ga.init = h->init_stage;
+    const auv_scene_params& p = h->gen_params;
+    ga.extent = p.extent;
+    ga.r_lo = p.r_lo;
+    ga.r_hi = p.r_hi;
+    ga.w_lo = p.w_lo;
+    ga.w_hi = p.w_hi;
+    ga.s_lo = p.s_lo;
+    ga.s_hi = p.s_hi;
+    ga.clearance = p.clearance;
+    ga.path_length = p.path_length;
+    const long long work = (long long)d.V * (1 + d.C + d.P);
+    hipLaunchKernelGGL(k_scenegen, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, ga);
+    HIP_TRY(h, hipGetLastError());
+    return AUV_OK;
+}
+
 // the attached network as a launch of its own, on the perception buffer
 int launch_cnn(auv_sim* h, hipStream_t st) {
     CnnArgs ca;
@@ -217,12 +253,18 @@ int launch_cnn(auv_sim* h, hipStream_t st) {
 // do_step is set.
 int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const double* action) {
     const Dims& d = h->d;
+    if (do_step && h->auto_reset && h->regenerate) {
+        // new scenes for the envs that k_vessel is about to restart
+        int rc = launch_scenegen(h, st, bp<uint8_t>(h, AUV_BUF_DONE));
+        if (rc) return rc;
+    }
     VesselArgs va;
     va.V = d.V;
     va.do_step = do_step;
     va.auto_reset = h->auto_reset;
     va.done = bp<uint8_t>(h, AUV_BUF_DONE);
     va.init = h->init_stage;
+    va.episode = bp<int32_t>(h, AUV_BUF_EPISODE);
     va.C = d.C;
     va.P = d.P;
     va.circles = bp<double>(h, AUV_BUF_CIRCLES);
@@ -527,6 +569,7 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     chk(alloc_buf(h, AUV_BUF_CIRCLES, AUV_F64, {V, C, 5}));
     chk(alloc_buf(h, AUV_BUF_POLY_POSE, AUV_F64, {V, P, 6}));
     chk(alloc_buf(h, AUV_BUF_REWARD, AUV_F64, {V}));
+    chk(alloc_buf(h, AUV_BUF_EPISODE, AUV_I32, {V}));
     chk(alloc_buf(h, AUV_BUF_CNN_OUT, AUV_F32, {V, 12}));  // widest head; the shape follows the attached network
     chk(alloc_raw(h, &h->poly_verts, (size_t)V * P * NV * 2));
     chk(alloc_raw(h, &h->poly_nv, (size_t)V * P));
@@ -624,15 +667,43 @@ int auv_set_scene(auv_handle h, int32_t env_begin, int32_t env_count, const doub
     return AUV_OK;
 }
 
+int auv_generate_scene(auv_handle h, uint64_t seed, const auv_scene_params* params, void* stream) {
+    if (!h) return AUV_ERR_ARG;
+    const Dims& d = h->d;
+    if (d.P > 0 && d.NV < 5) return fail(h, AUV_ERR_ARG, "auv_generate_scene: ships need n_verts >= 5, batch has %d", d.NV);
+    auv_scene_params p = {200.0, 5.0, 30.0, 5.0, 20.0, 0.3, 1.2, 25.0, 800.0};
+    if (params) p = *params;
+    if (!(p.extent > 0.0) || !(p.r_lo > 0.0) || !(p.r_hi >= p.r_lo) || !(p.w_lo > 0.0) || !(p.w_hi >= p.w_lo) ||
+        !(p.s_lo >= 0.0) || !(p.s_hi >= p.s_lo) || !(p.clearance >= 0.0) || !(p.path_length > 0.0))
+        return fail(h, AUV_ERR_ARG, "auv_generate_scene: parameters out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = pick(h, stream);
+    h->gen_seed = seed;
+    h->gen_params = p;
+    HIP_TRY(h, hipMemsetAsync(bp<int32_t>(h, AUV_BUF_EPISODE), 0, (size_t)d.V * sizeof(int32_t), st));
+    int rc = launch_scenegen(h, st, nullptr);
+    if (rc) return rc;
+    h->have_generator = true;
+    h->have_scene = true;
+    h->have_init = true;
+    h->have_state = false;  // the live obstacle records follow at the next full reset
+    return AUV_OK;
+}
+
 int auv_reset(auv_handle h, const uint8_t* mask, const double* init_state, void* stream) {
-    if (!h || !init_state) return fail(h, AUV_ERR_ARG, "auv_reset: null argument");
+    if (!h) return AUV_ERR_ARG;
+    if (!init_state && !h->have_init)
+        return fail(h, AUV_ERR_ARG, "auv_reset: init_state is NULL and no initial states are on the device yet");
     int rc = ready_to_run(h, false);
     if (rc) return rc;
     if (mask && !h->have_state) return fail(h, AUV_ERR_STATE, "auv_reset: first reset must cover all envs (mask == NULL)");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = pick(h, stream);
     const Dims& d = h->d;
-    HIP_TRY(h, hipMemcpyAsync(h->init_stage, init_state, (size_t)d.V * 6 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (init_state) {
+        HIP_TRY(h, hipMemcpyAsync(h->init_stage, init_state, (size_t)d.V * 6 * sizeof(double), hipMemcpyHostToDevice, st));
+        h->have_init = true;
+    }
     if (mask) HIP_TRY(h, hipMemcpyAsync(h->mask_stage, mask, (size_t)d.V, hipMemcpyHostToDevice, st));
     ResetArgs ra;
     ra.d = d;
@@ -791,6 +862,12 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
             if (value && h->lidar_mode != AUV_LIDAR_RASTER)
                 return fail(h, AUV_ERR_ARG, "auv_set_option: in-step restart needs the rasterising path");
             h->auto_reset = value;
+            return AUV_OK;
+        case AUV_OPT_REGENERATE:
+            if (value != 0 && value != 1) return fail(h, AUV_ERR_ARG, "auv_set_option: AUV_OPT_REGENERATE takes 0 or 1");
+            if (value && !h->have_generator)
+                return fail(h, AUV_ERR_STATE, "auv_set_option: call auv_generate_scene before AUV_OPT_REGENERATE");
+            h->regenerate = value;
             return AUV_OK;
         case AUV_OPT_RASTER_TILE:
             if (value < 0 || value > 64)

@@ -41,9 +41,13 @@ class VecAuvEnv:
                      (its action is ignored, reward 0); the step that ends an episode
                      returns the terminal observation with done = True;
       False          done envs keep stepping until `reset()`.
+    scene None: scenes, paths and initial states come from the device-side
+    generator (`seed`, `gen_params`); with auto_reset="device" every restarting
+    env then gets a new scene for its next episode, still without the host.
     """
 
-    def __init__(self, cfg: dict, scene: dict, device: int = 0, auto_reset=True):
+    def __init__(self, cfg: dict, scene: dict | None, device: int = 0, auto_reset=True, seed: int = 0,
+                 gen_params: dict | None = None):
         import torch
 
         from . import _lib
@@ -54,12 +58,19 @@ class VecAuvEnv:
         self.num_envs = int(cfg["n_envs"])
         self.device = torch.device("cuda", device)
         self.sim = AuvSim(cfg, device=device)
-        self.sim.set_scene(scene)
+        if scene is None:
+            self.sim.generate_scene(seed, gen_params)
+        else:
+            self.sim.set_scene(scene)
         self.auto_reset = "host" if auto_reset is True else auto_reset
         if self.auto_reset not in ("host", "device", False):
             raise ValueError("auto_reset must be True, 'host', 'device' or False")
         if self.auto_reset == "device":
             self.sim.set_option(_lib.OPT_AUTO_RESET, 1)
+            if scene is None:
+                self.sim.set_option(_lib.OPT_REGENERATE, 1)
+        elif scene is None and self.auto_reset == "host":
+            raise ValueError("generated scenes restart on the device: use auto_reset='device' or False")
         R = int(cfg["n_rays"])
         self.observation_space = DictSpace({
             "perception": Box(0.0, 1.0, (1, R)),
@@ -71,7 +82,7 @@ class VecAuvEnv:
         self._reward = self.sim.tensor("reward")
         self._done = self.sim.tensor("done")
         self._action = self.sim.tensor("action")   # f64 [2,V] staging
-        self._init_state = np.ascontiguousarray(scene["init_state"], dtype=np.float64)
+        self._init_state = None if scene is None else np.ascontiguousarray(scene["init_state"], dtype=np.float64)
         self.episodes_done = 0
 
     def _stream(self):

@@ -112,8 +112,25 @@ class AuvSim:
         self._check(self._lib.auv_set_scene(self._h, int(env_begin), n, _ptr(circles), _ptr(pose),
                                             _ptr(verts), _ptr(nv), _ptr(head), _ptr(path)))
 
+    def generate_scene(self, seed: int, params: dict | None = None, stream=None):
+        """Scene, paths and initial states of every env from the device-side
+        generator (episode 0); follow with `reset(None)`.  `params` overrides
+        the defaults by name (extent, r_lo, r_hi, w_lo, w_hi, s_lo, s_hi,
+        clearance, path_length)."""
+        p = None
+        if params is not None:
+            full = dict(extent=200.0, r_lo=5.0, r_hi=30.0, w_lo=5.0, w_hi=20.0, s_lo=0.3, s_hi=1.2,
+                        clearance=25.0, path_length=800.0)
+            unknown = set(params) - set(full)
+            if unknown:
+                raise ValueError(f"unknown generator parameters {sorted(unknown)}")
+            full.update(params)
+            p = C.byref(_lib.AuvSceneParams(**{k: float(v) for k, v in full.items()}))
+        self._check(self._lib.auv_generate_scene(self._h, int(seed) & (2 ** 64 - 1), p, _stream_handle(stream)))
+
     def reset(self, init_state, mask=None, stream=None):
-        init = _f64(init_state, (6, self.V))
+        """init_state None: the initial states already on the device (generator or last reset)."""
+        init = None if init_state is None else _f64(init_state, (6, self.V))
         m = None
         if mask is not None:
             m = np.ascontiguousarray(np.asarray(mask).astype(bool), dtype=np.uint8)

@@ -97,7 +97,8 @@ typedef enum auv_buffer {
     AUV_BUF_POLY_POSE = 19,  /* f64 [V,P,6] X,Y,cos h,sin h,vx,vy */
     AUV_BUF_REWARD = 20,     /* f64 [V]   reward of the last step (0 after reset) */
     AUV_BUF_CNN_OUT = 21,    /* f32 [V,out_dim] output of the attached network (auv_attach_cnn); zeros, out_dim 12, before */
-    AUV_BUF_COUNT = 22
+    AUV_BUF_EPISODE = 22,    /* i32 [V]   in-step restarts of the env so far (= its episode number for the generator) */
+    AUV_BUF_COUNT = 23
 } auv_buffer;
 
 /* Tunables (auv_set_option).  Both LiDAR kernels produce identical bits; the
@@ -107,11 +108,14 @@ typedef enum auv_option {
     AUV_OPT_LIDAR_MODE = 0,   /* AUV_LIDAR_RASTER (default) | AUV_LIDAR_ALL_PAIRS */
     AUV_OPT_RASTER_TILE = 1,  /* envs per workgroup of the rasterising kernel; 0 = auto */
     AUV_OPT_SENSE_BLOCK = 2,  /* threads per k_sense workgroup: 64, 128, 256 or 512 */
-    AUV_OPT_AUTO_RESET = 3    /* 1: an env whose done flag is set restarts INSIDE the next auv_step, with no
+    AUV_OPT_AUTO_RESET = 3,   /* 1: an env whose done flag is set restarts INSIDE the next auv_step, with no
                                * host round trip: its action is ignored, the vessel takes the initial state
                                * of the most recent auv_reset call, its step counter is cleared, its
                                * obstacles return to their uploaded poses, its reward is 0 and its flags
                                * are those of the fresh state (rasterising path only; default 0) */
+    AUV_OPT_REGENERATE = 4    /* 1: with AUV_OPT_AUTO_RESET, a restarting env also gets a NEW scene, path and
+                               * initial state from the generator (auv_generate_scene must have been called),
+                               * for episode number AUV_BUF_EPISODE + 1; default 0: same scene every episode */
 } auv_option;
 #define AUV_LIDAR_RASTER 0
 #define AUV_LIDAR_ALL_PAIRS 1
@@ -141,9 +145,31 @@ int auv_set_scene(auv_handle h, int32_t env_begin, int32_t env_count,
                   const double* poly_verts, const int32_t* poly_nv,
                   const double* poly_heading, const double* path);
 
-/* gym reset(): host init_state f64 [6,V]; mask u8 [V] or NULL (= all envs).
+/* Parameters of the scenario generator (metres, m/s). */
+typedef struct auv_scene_params {
+    double extent;       /* obstacle centres ~ U(-extent, extent)^2 round the vessel at the origin */
+    double r_lo, r_hi;   /* circle radius ~ U */
+    double w_lo, w_hi;   /* ship beam ~ U (the hull is 2 beams long) */
+    double s_lo, s_hi;   /* ship speed ~ U, heading ~ U(-pi, pi) */
+    double clearance;    /* no hull starts nearer than this to the vessel */
+    double path_length;  /* straight path from the origin along the vessel's initial heading */
+} auv_scene_params;
+
+/* Generate scene, paths and initial states of EVERY env on the device, for
+ * episode 0 (clears AUV_BUF_EPISODE): `n_circles` static circles and `n_polys`
+ * five-vertex ships per env (needs n_verts >= 5 when n_polys > 0), each number
+ * a function of (seed, env, episode, purpose, index) through Philox4x32-10.
+ * params == NULL: extent 200, radius 5..30, beam 5..20, speed 0.3..1.2,
+ * clearance 25, path 800.  Afterwards auv_reset may be called with
+ * init_state == NULL.  Replaces the scenario constructor of the env
+ * (MovingObstaclesNoRules, the scenario named by the reference's data files
+ * data/ *_MovingObstaclesNoRules.csv).  Asynchronous on `stream`. */
+int auv_generate_scene(auv_handle h, uint64_t seed, const auv_scene_params* params, void* stream);
+
+/* gym reset(): host init_state f64 [6,V] (NULL: the initial states of the last
+ * reset call or of the generator); mask u8 [V] or NULL (= all envs).
  * Resets the selected envs (vessel state, step counter, obstacles back to
- * their uploaded poses), then senses.
+ * their uploaded or generated poses), then senses.
  * Observation consumer: radarCNN.py:270-280. */
 int auv_reset(auv_handle h, const uint8_t* mask, const double* init_state, void* stream);
 

@@ -497,6 +497,11 @@ class OracleEnv:
         # in-step restart: an env whose done flag is set is reset by the next
         # step() instead of being integrated (reward 0, action ignored)
         self.auto_reset = False
+        # ... and, with `regenerate`, gets a new scene from the generator
+        # (oracle/scene_oracle.py) for its next episode number
+        self.regenerate = False
+        self.episode = np.zeros(V, dtype=np.int32)
+        self.generator = None   # (seed, params)
 
     def set_scene(self, circles, poly_pose, poly_verts, poly_nv, poly_heading=None):
         self.circles = np.array(circles, dtype=np.float64, copy=True)
@@ -512,8 +517,22 @@ class OracleEnv:
     def set_path(self, path):
         self.path = np.array(path, dtype=np.float64, copy=True)
 
+    def generate_scene(self, seed, params=None):
+        """Scene, paths and initial states of every env from the generator, episode 0."""
+        from oracle import scene_oracle
+
+        V = self.state.shape[1]
+        C, P, NV = self.cfg["n_circles"], self.cfg["n_polys"], self.cfg["n_verts"]
+        self.generator = (int(seed), params)
+        self.episode[:] = 0
+        sc = scene_oracle.generate(int(seed), np.arange(V), self.episode, C, P, NV, params)
+        self.set_scene(sc["circles"], sc["poly_pose"], sc["poly_verts"], sc["poly_nv"], sc["poly_heading"])
+        self.set_path(sc["path"])
+        self.init0 = sc["init_state"]
+
     def reset(self, init_state, mask=None):
-        init_state = np.asarray(init_state, dtype=np.float64)
+        # None: the initial states of the last reset call or of the generator
+        init_state = self.init0 if init_state is None else np.asarray(init_state, dtype=np.float64)
         self.init0 = init_state.copy()
         # a reset also puts the env's obstacles back where they were uploaded
         if mask is None:
@@ -567,10 +586,24 @@ class OracleEnv:
         self.state = step_dynamics(self.state, action, cfg)
         self.t_step = self.t_step + 1
         if restart.any():
+            self.episode[restart] += 1
+            if self.regenerate:
+                from oracle import scene_oracle
+
+                C, P, NV = cfg["n_circles"], cfg["n_polys"], cfg["n_verts"]
+                sc = scene_oracle.generate(self.generator[0], np.nonzero(restart)[0], self.episode[restart], C, P, NV,
+                                           self.generator[1])
+                self.circles0[restart] = sc["circles"]
+                self.poly_pose0[restart] = sc["poly_pose"]
+                self.poly_verts[restart] = sc["poly_verts"]
+                self.poly_nv[restart] = sc["poly_nv"]
+                self.poly_heading[restart] = sc["poly_heading"]
+                self.path[restart] = sc["path"]
+                self.init0[:, restart] = sc["init_state"]
             self.state[:, restart] = self.init0[:, restart]
             self.t_step[restart] = 0
-            self.circles[restart, :, :2] = self.circles0[restart, :, :2]
-            self.poly_pose[restart, :, :2] = self.poly_pose0[restart, :, :2]
+            self.circles[restart] = self.circles0[restart]
+            self.poly_pose[restart] = self.poly_pose0[restart]
         self.sense(is_step=True)
         self.reward[restart] = 0.0
 

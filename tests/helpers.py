@@ -13,7 +13,7 @@ PAIRS = {
     "own": "own", "collision": "collision", "reached_goal": "reached_goal",
     "truncated": "truncated", "done": "done", "min_dist": "min_dist", "min_idx": "min_idx",
     "along": "along", "t_step": "t_step", "circles": "circles", "poly_pose": "poly_pose",
-    "reward": "reward",
+    "reward": "reward", "episode": "episode",
 }
 
 

@@ -12,6 +12,8 @@ import numpy as np
 import pytest
 
 from gym_auv_amd import params, scenarios
+from gym_auv_amd.sim import AuvSim
+from oracle import auv_oracle as O
 from tests.helpers import assert_all_equal, make_oracle, make_sim, same_bits
 
 pytestmark = pytest.mark.gpu
@@ -130,6 +132,50 @@ def test_in_step_restart_matches_oracle():
     # the cross-check path has no in-step restart and says so
     with pytest.raises(Exception, match="all-pairs"):
         sim.set_option(_lib.OPT_LIDAR_MODE, _lib.LIDAR_ALL_PAIRS)
+    sim.close()
+
+
+def test_generated_scenes_and_regeneration_match_oracle():
+    """The device-side scenario generator against its numpy twin: the generated
+    scene itself, then 100 steps in which finished episodes restart in-step with
+    a NEW scene for their next episode number (no host round trip); every
+    buffer, the live obstacle records and the episode counters must agree."""
+    from gym_auv_amd import _lib
+
+    V = 133
+    cfg = params.make_config(V, 5, 6, 6, max_steps=25, goal_radius=5.0)
+    gp = dict(extent=70.0, w_lo=8.0, w_hi=25.0, path_length=14.0, clearance=4.0)
+    sim = AuvSim(cfg)
+    env = O.OracleEnv(cfg, params.ray_table(cfg["n_rays"]))
+    sim.generate_scene(0x9E3779B97F4A7C15, gp)
+    env.generate_scene(0x9E3779B97F4A7C15, gp)
+    sim.reset(None)
+    env.reset(None)
+    assert_all_equal(sim, env, "after generation + reset")
+    sim.set_option(_lib.OPT_AUTO_RESET, 1)
+    sim.set_option(_lib.OPT_REGENERATE, 1)
+    env.auto_reset = env.regenerate = True
+    acts = scenarios.random_actions(V, 100, seed=26)
+    acts[:, 0] = 1.0
+    acts[:, 1] *= 0.1
+    seen = np.zeros(3, dtype=bool)
+    for k in range(100):
+        sim.step_host(acts[k])
+        env.step(acts[k])
+        assert_all_equal(sim, env, f"after step {k + 1}")
+        seen |= [env.collision.any(), env.reached_goal.any(), env.truncated.any()]
+    assert env.episode.min() >= 1 and env.episode.max() >= 4 and seen.all(), (env.episode.min(), env.episode.max(), seen)
+    # defaults (params == NULL) and a second seed give the oracle's scene too
+    sim.generate_scene(5)
+    env.generate_scene(5)
+    sim.reset(None)
+    env.reset(None)
+    assert_all_equal(sim, env, "default parameters")
+    sim.close()
+    # ships need five vertex slots
+    sim = AuvSim(params.make_config(4, 1, 1, 4))
+    with pytest.raises(Exception, match="n_verts"):
+        sim.generate_scene(1)
     sim.close()
 
 
@@ -294,4 +340,12 @@ def test_vec_env_gym_contract():
     assert done.all() and "terminal_mask" not in info        # truncated after 3 steps
     obs, rew, done, info = venv.step(a)
     assert (rew == 0).all() and (venv.sim.read("t_step") == 0).all()
+    venv.close()
+    # scenes from the device-side generator, a new one per episode
+    venv = VecAuvEnv(cfg2, None, auto_reset="device", seed=11)
+    venv.reset()
+    first = venv.sim.read("circles").copy()
+    for k in range(4):
+        obs, rew, done, info = venv.step(a)
+    assert (venv.sim.read("episode") == 1).all() and not np.array_equal(venv.sim.read("circles"), first)
     venv.close()
