@@ -48,48 +48,41 @@ def sense_bytes_per_env(R, C, P, NV):
 VESSEL_BYTES_PER_ENV = 48 + 48 + 16 + 48 + 64 + 16 + 8 + 8 + 24 + 2 + 8  # state rw, action, path, record, own, along rw, nav, flags, t_step
 
 
-def _cpu_worker(job):
-    """One process of the CPU baseline: `n_envs` envs of the workload (its own
-    seed offset) stepped `steps` times by the numpy oracle.  Returns (stepping
-    seconds, wall-clock start, wall-clock end)."""
-    name, n_envs, steps, rank = job
-    from gym_auv_amd import scenarios
+def cpu_baseline(name, n_envs, steps, threads):
+    """The oracle on a bounded sample of the same workload, on the host cores:
+    the C restatement (oracle/auv_oracle.c, scalar per env, all ray-primitive
+    pairs) with `threads` threads over disjoint env ranges, plus, for scale,
+    the numpy oracle on one core over a smaller sample."""
+    from gym_auv_amd import params, scenarios
+    from oracle import c_oracle
     from tests.helpers import make_oracle
 
-    cfg, scene = scenarios.make_workload(name, n_envs=n_envs, rank=rank)
-    env = make_oracle(cfg, scene)
+    cfg, scene = scenarios.make_workload(name, n_envs=n_envs)
+    env = c_oracle.COracleEnv(cfg, params.ray_table(cfg["n_rays"]), threads=threads)
+    env.set_scene(scene["circles"], scene["poly_pose"], scene["poly_verts"], scene["poly_nv"],
+                  scene.get("poly_heading"))
+    env.set_path(scene["path"])
     env.reset(scene["init_state"])
-    acts = scenarios.random_actions(n_envs, steps, seed=7 + rank)
-    w0 = time.time()
+    acts = scenarios.random_actions(n_envs, steps, seed=7)
     t0 = time.perf_counter()
     for k in range(steps):
         env.step(acts[k])
-    return time.perf_counter() - t0, w0, time.time()
-
-
-def cpu_baseline(name, n_envs, steps, procs):
-    """The numpy oracle on a bounded sample of the same workload: `procs`
-    processes (spawned, so none inherits the GPU context), each one core, each
-    stepping its own `n_envs` envs; the rate is all their env-steps over the span
-    from the first start to the last end.  The one-core rate is process 0's."""
-    import multiprocessing as mp
-
-    from gym_auv_amd import scenarios
-
-    R = scenarios.WORKLOADS[name]["R"]
-    jobs = [(name, n_envs, steps, r) for r in range(procs)]
-    if procs == 1:
-        res = [_cpu_worker(jobs[0])]
-    else:
-        with mp.get_context("spawn").Pool(procs) as pool:
-            res = pool.map(_cpu_worker, jobs, chunksize=1)
-    span = max(r[2] for r in res) - min(r[1] for r in res)
-    total = n_envs * steps * procs
-    return {"value": total / span, "unit": "env-steps/s", "cores": procs, "kind": "port",
-            "sample": f"{procs} processes x {n_envs} envs x {steps} steps of {name} (numpy fp64 oracle, one core "
-                      f"each; substitute for the absent reference env), {span:.1f} s",
-            "rays_per_s": total * R / span,
-            "one_core": {"value": n_envs * steps / res[0][0], "unit": "env-steps/s"}}
+    dt = time.perf_counter() - t0
+    env.close()
+    n_np, s_np = min(n_envs, 2048), min(steps, 10)
+    cfg2, scene2 = scenarios.make_workload(name, n_envs=n_np)
+    env2 = make_oracle(cfg2, scene2)
+    env2.reset(scene2["init_state"])
+    t1 = time.perf_counter()
+    for k in range(s_np):
+        env2.step(acts[k][:, :n_np])
+    dt_np = time.perf_counter() - t1
+    return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n_envs} envs x {steps} steps of {name}, C oracle (oracle/auv_oracle.c), {threads} threads, "
+                      f"{dt:.1f} s; substitute for the absent reference env",
+            "rays_per_s": n_envs * steps * cfg["n_rays"] / dt,
+            "numpy_one_core": {"value": n_np * s_np / dt_np, "unit": "env-steps/s",
+                               "sample": f"{n_np} envs x {s_np} steps, {dt_np:.1f} s"}}
 
 
 def measured_traffic(key, kernel):
@@ -121,10 +114,10 @@ def main():
     ap.add_argument("--gather-scans", action="store_true",
                     help="also gather the final scans of every rank on rank 0 once per rollout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-procs", type=int, default=0,
-                    help="processes of the CPU baseline, one core each (0 = the CPUs this process may use, at most 16)")
-    ap.add_argument("--cpu-envs", type=int, default=4096)
-    ap.add_argument("--cpu-steps", type=int, default=60)
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the CPU baseline (0 = the CPUs this process may use, at most 16)")
+    ap.add_argument("--cpu-envs", type=int, default=32768)
+    ap.add_argument("--cpu-steps", type=int, default=40)
     args = ap.parse_args()
 
     import torch
@@ -316,8 +309,8 @@ def main():
                 "flops_per_launch": flops, "avg_launch_ms": sense_s * 1e3,
                 "note": "fp64 vector (non-MFMA) roofline; (16*circles + 18*edges) flop per ray"}
         if not args.no_cpu_baseline and world == 1:
-            procs = args.cpu_procs or max(1, min(16, len(os.sched_getaffinity(0))))
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_envs, args.cpu_steps, procs)
+            threads = args.cpu_threads or max(1, min(16, len(os.sched_getaffinity(0))))
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_envs, args.cpu_steps, threads)
         print(json.dumps(out), flush=True)
     sim.close()
     if world > 1:
