@@ -97,6 +97,19 @@ def measured_traffic(key, kernel):
         return None
 
 
+def measured_valu_insts(key, kernel):
+    """VALU wave-instructions per launch from the committed PMC summary, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return float(json.load(f)[key][kernel]["valu_insts"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+# one VALU instruction per SIMD every 4 cycles (a 64-wide wave on 16 lanes), 4 SIMDs x 256 CUs, 2.4 GHz
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,6 +303,13 @@ def main():
                 "avg_launch_ms": sense_s * 1e3,
                 "note": "rasterised LiDAR + encounter + obstacle advance in one pass over the scene; "
                         "algorithmic bytes = scene + vessel record in, positions + all outputs out"}
+            vi = measured_valu_insts(tkey, "k_sense")
+            if vi is not None:
+                out["valu_issue"] = {
+                    "kernel": "k_sense", "achieved": vi / sense_s, "peak": VALU_ISSUE_PEAK, "unit": "wave-instr/s",
+                    "frac": vi / sense_s / VALU_ISSUE_PEAK, "insts_per_launch": vi,
+                    "note": "executed VALU wave-instructions (PMC, profiles/) over this run's launch time, against "
+                            "the issue rate of 1024 SIMDs at 2.4 GHz: what actually bounds the kernel"}
             vb = float(VESSEL_BYTES_PER_ENV) * V
             out["roofline_vessel"] = {
                 "kernel": "k_vessel", "bound": "hbm", "achieved": vb / vessel_s / 1e9, "peak": HBM_PEAK_GBS,
