@@ -198,22 +198,33 @@ __device__ __forceinline__ void cnn_forward(const float* x, int x_stride, float*
     }
 }
 
+// dynamic LDS of one k_cnn workgroup: the scans, then two activation buffers per scan
+__host__ __device__ inline size_t cnn_lds_bytes(int kind) {
+    return (size_t)kCnnScans * (kCnnBuf + 2 * cnn_buf_floats(kind)) * sizeof(float);
+}
+
 __global__ __launch_bounds__(256) void k_cnn(CnnArgs a) {
-    __shared__ float lds[kCnnScans][3][kCnnBuf];
+    extern __shared__ __align__(16) float cnn_lds[];
+    const int nb = cnn_buf_floats(a.kind);
+    float* xs = cnn_lds;                       // [kCnnScans][kCnnBuf], rows 16-B aligned
+    float* act = cnn_lds + kCnnScans * kCnnBuf;  // [kCnnScans][2][nb]
     const int tid = threadIdx.x;
     const long long s0 = (long long)blockIdx.x * kCnnScans;
     const int ns = (int)((a.B - s0) < kCnnScans ? (a.B - s0) : kCnnScans);
-    // coalesced load of the tile's scans
-    for (int i = tid; i < ns * kCnnLen; i += blockDim.x) {
-        const int s = i / kCnnLen;
-        lds[s][0][i - s * kCnnLen] = a.scans[s0 * kCnnLen + i];
+    // coalesced 16-B loads of the tile's scans (180 floats = 45 float4 per scan; the
+    // tile starts at a multiple of 16 * 720 B)
+    const float4* src = reinterpret_cast<const float4*>(a.scans + s0 * kCnnLen);
+    for (int i = tid; i < ns * (kCnnLen / 4); i += blockDim.x) {
+        const int s = i / (kCnnLen / 4);
+        const int c = i - s * (kCnnLen / 4);
+        *reinterpret_cast<float4*>(xs + s * kCnnBuf + 4 * c) = src[i];
     }
     __syncthreads();
     // 16 lanes per scan, one scan per lane group
     const int s = tid / kCnnLanes;
     const int lane = tid - s * kCnnLanes;
     if (s >= ns) return;
-    cnn_forward<true, false>(lds[s][0], 0, lds[s][1], lds[s][2], 0, 1, a.w,
+    cnn_forward<true, false>(xs + s * kCnnBuf, 0, act + (size_t)s * 2 * nb, act + ((size_t)s * 2 + 1) * nb, 0, 1, a.w,
                              a.out + (s0 + s) * cnn_out_dim(a.kind, a.head), a.kind, a.head, lane, kCnnLanes);
 }
 

@@ -243,7 +243,8 @@ int launch_cnn(auv_sim* h, hipStream_t st) {
     ca.B = h->d.V;
     ca.kind = h->cnn_kind;
     ca.head = h->cnn_head;
-    hipLaunchKernelGGL(k_cnn, dim3((unsigned)((h->d.V + kCnnScans - 1) / kCnnScans)), dim3(256), 0, st, ca);
+    hipLaunchKernelGGL(k_cnn, dim3((unsigned)((h->d.V + kCnnScans - 1) / kCnnScans)), dim3(256),
+                       cnn_lds_bytes(ca.kind), st, ca);
     HIP_TRY(h, hipGetLastError());
     return AUV_OK;
 }
@@ -1018,7 +1019,9 @@ int auv_cnn_forward(auv_cnn_handle c, const float* scans, int64_t n_scans, int32
     a.kind = c->kind;
     a.head = head;
     const unsigned blocks = (unsigned)((n_scans + kCnnScans - 1) / kCnnScans);
-    hipLaunchKernelGGL(k_cnn, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if ((reinterpret_cast<uintptr_t>(scans) & 15u) != 0)
+        return cnn_fail(c, AUV_ERR_ARG, "auv_cnn_forward: scans must be 16-byte aligned");
+    hipLaunchKernelGGL(k_cnn, dim3(blocks), dim3(256), cnn_lds_bytes(a.kind), (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cnn_fail(c, AUV_ERR_DEVICE, "k_cnn launch failed: %s", hipGetErrorString(e));
     return AUV_OK;
