@@ -143,9 +143,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-rank path on a one-GPU box: AUV_BENCH_REHEARSE=1 puts
+    # every rank on cuda:0 and uses gloo (RCCL refuses two ranks on one device)
+    rehearse = os.environ.get("AUV_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
@@ -223,6 +231,8 @@ def main():
             if net is not None:
                 net.forward(per_t, "features", out=feats)
         torch.cuda.synchronize(dev)
+    # the measured rollout starts from the reset state, whatever the spin did to the episodes
+    sim.reset(scene["init_state"], stream=stream)
     for k in range(args.warmup):
         sim.step_device(ptrs[k % n_act], stream=stream)
     episode_stats()   # loads torch's reduction kernels / sets up the communicator outside the timed region
