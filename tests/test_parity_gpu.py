@@ -285,6 +285,39 @@ def test_full_size_batch_against_oracle_sample():
     sim.close()
 
 
+@pytest.mark.parametrize("name,steps,mode", [("cfg3_65536_moving", 10, 0), ("cfg3_65536_moving", 3, 1),
+                                             ("cfg2_4096_static", 10, 0), ("cfg5_dense_720", 2, 0)],
+                         ids=["cfg3-raster", "cfg3-allpairs", "cfg2", "cfg5"])
+def test_full_size_batch_every_env_against_c_oracle(name, steps, mode):
+    """The benchmark configurations at their FULL sizes (65,536 vessels; 4,096
+    vessels with 720 rays and 256 obstacles), every env and every buffer, bit
+    for bit, against the C restatement of the oracle (itself pinned to the numpy
+    text by tests/test_c_oracle_cpu.py) run on the host cores, after the reset
+    and after every step."""
+    import os
+
+    from oracle import c_oracle
+
+    cfg, scene = scenarios.make_workload(name)
+    V = cfg["n_envs"]
+    sim = make_sim(cfg, scene, lidar_mode=mode)
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    env = c_oracle.COracleEnv(cfg, params.ray_table(cfg["n_rays"]), threads=threads)
+    env.set_scene(scene["circles"], scene["poly_pose"], scene["poly_verts"], scene["poly_nv"], scene["poly_heading"])
+    env.set_path(scene["path"])
+    env.episode = np.zeros(V, dtype=np.int32)
+    sim.reset(scene["init_state"])
+    env.reset(scene["init_state"])
+    assert_all_equal(sim, env, "full batch after reset")
+    acts = scenarios.random_actions(V, steps, seed=43)
+    for k in range(steps):
+        sim.step_host(acts[k])
+        env.step(acts[k])
+        assert_all_equal(sim, env, f"full batch after step {k + 1}")
+    env.close()
+    sim.close()
+
+
 def test_device_action_pointer_and_dlpack_views():
     import torch
 
