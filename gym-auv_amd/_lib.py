@@ -35,7 +35,7 @@ BUFFER_NAMES = {
 }
 
 # auv_option
-OPT_LIDAR_MODE, OPT_RASTER_TILE, OPT_SENSE_BLOCK, OPT_AUTO_RESET, OPT_REGENERATE = 0, 1, 2, 3, 4
+OPT_LIDAR_MODE, OPT_RASTER_TILE, OPT_SENSE_BLOCK, OPT_AUTO_RESET, OPT_REGENERATE, OPT_META_EVERY = 0, 1, 2, 3, 4, 5
 LIDAR_RASTER, LIDAR_ALL_PAIRS = 0, 1
 
 # CNN consumers

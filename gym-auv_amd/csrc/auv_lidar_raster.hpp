@@ -47,6 +47,11 @@ __device__ __forceinline__ float fast_atan2f(float y, float x) {
     return y < 0.0f ? -a : a;
 }
 
+// square root for the candidate intervals only: the bare hardware instruction
+// (1 ulp), without the scaling and the two correction steps that make sqrtf
+// exact; its error is six orders of magnitude inside the interval margins
+__device__ __forceinline__ float fast_sqrtf(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 // i / d for 0 <= i < 2^20 and 1 <= d < 2^16 through one fp32 multiply
 // (inv_d = 1.0f / d): (i + 0.5) / d is at least 0.5/d away from an integer,
 // far more than the rounding error of the product at these magnitudes.

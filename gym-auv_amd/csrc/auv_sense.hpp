@@ -124,6 +124,7 @@ struct SenseArgs {
     int TE;       // envs per workgroup
     int cap;      // pair-list slots per round
     int is_step;  // 1: advance obstacles, finish the reward; 0: after reset / plain sense
+    int with_meta;  // 0: bearing, course and risk of the obstacles are not refreshed by this pass
     const double* state;
     const double* envrec;
     double* circles;    // [V,C,5]  positions updated in place when is_step
@@ -415,11 +416,11 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
             // absent slot
         } else if (!(fmm > fr * fr * 1.001f)) {
             iv.y = R;  // vessel inside or touching: every ray can hit
-        } else if (sqrtf(fmm) - fr > frange) {
+        } else if (fast_sqrtf(fmm) - fr > frange) {
             // wholly beyond sensor range
         } else {
             const float xc = scan_index(fast_atan2f(fmy, fmx), (float)psi, inv_delta);
-            const float hw = fast_atan2f(fr, sqrtf(fmm - fr * fr)) * inv_delta;
+            const float hw = fast_atan2f(fr, fast_sqrtf(fmm - fr * fr)) * inv_delta;
             iv = make_interval(xc - hw, xc + hw, R, margin);
         }
         meta[i] = pack_meta(iv.x, iv.y, el, j);
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
             // candidate rays: the arc between the bearings of the two endpoints
             const float fax = (float)ax, fay = (float)ay, fex = (float)ex, fey = (float)ey;
             const float fbx = fax + fex, fby = fay + fey;
-            const float dmin = sqrtf((float)dd);
+            const float dmin = fast_sqrtf((float)dd);
             const float aa = fax * fax + fay * fay, bb = fbx * fbx + fby * fby;
             if (dmin > frange) {
                 // wholly beyond sensor range: stays empty
@@ -579,7 +580,8 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
         // when an env's obstacles sit in an aligned power-of-two group of lanes
         // of one wave, its nearest obstacle is a shuffle reduction
         const bool lanes_per_env = O > 0 && (O & (O - 1)) == 0 && TE * O <= 64;
-        for (int task = wave; task < 4; task += n_waves) {
+        const int n_tasks = a.with_meta ? 4 : 1;
+        for (int task = wave; task < n_tasks; task += n_waves) {
             for (int i0 = 0; i0 < n_obst || (task == 0 && i0 == 0); i0 += 64) {
                 const int i = i0 + lane;
                 const bool live = i < n_obst;

@@ -74,6 +74,8 @@ struct auv_sim {
     int raster_want = 0;  // envs per workgroup asked for (0 = automatic)
     int auto_reset = 0;   // done envs restart inside the next step
     int regenerate = 0;   // ... with a newly generated scene
+    int meta_every = 1;   // steps between refreshes of bearing / course / risk (0: only outside steps)
+    long long step_count = 0;
     bool have_generator = false, have_init = false;
     uint64_t gen_seed = 0;
     auv_scene_params gen_params;
@@ -302,6 +304,8 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.TE = h->raster_te;
     sa.cap = h->raster_cap;
     sa.is_step = do_step;
+    if (do_step) h->step_count++;
+    sa.with_meta = !do_step || (h->meta_every > 0 && h->step_count % h->meta_every == 0);
     sa.state = bp<double>(h, AUV_BUF_STATE);
     sa.envrec = h->envrec;
     sa.circles = bp<double>(h, AUV_BUF_CIRCLES);
@@ -863,6 +867,11 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
             if (value && h->lidar_mode != AUV_LIDAR_RASTER)
                 return fail(h, AUV_ERR_ARG, "auv_set_option: in-step restart needs the rasterising path");
             h->auto_reset = value;
+            return AUV_OK;
+        case AUV_OPT_META_EVERY:
+            if (value < 0) return fail(h, AUV_ERR_ARG, "auv_set_option: AUV_OPT_META_EVERY must be >= 0");
+            h->meta_every = value;
+            h->step_count = 0;
             return AUV_OK;
         case AUV_OPT_REGENERATE:
             if (value != 0 && value != 1) return fail(h, AUV_ERR_ARG, "auv_set_option: AUV_OPT_REGENERATE takes 0 or 1");

@@ -113,9 +113,16 @@ typedef enum auv_option {
                                * of the most recent auv_reset call, its step counter is cleared, its
                                * obstacles return to their uploaded poses, its reward is 0 and its flags
                                * are those of the fresh state (rasterising path only; default 0) */
-    AUV_OPT_REGENERATE = 4    /* 1: with AUV_OPT_AUTO_RESET, a restarting env also gets a NEW scene, path and
+    AUV_OPT_REGENERATE = 4,   /* 1: with AUV_OPT_AUTO_RESET, a restarting env also gets a NEW scene, path and
                                * initial state from the generator (auv_generate_scene must have been called),
                                * for episode number AUV_BUF_EPISODE + 1; default 0: same scene every episode */
+    AUV_OPT_META_EVERY = 5    /* n: the per-obstacle bearing, course (AUV_BUF_META fields 3, 4) and AUV_BUF_RISK
+                               * are refreshed only by every n-th auv_step since this call (and by every
+                               * auv_reset / auv_sense); in between they keep their last values.  The
+                               * reference logs them about every 5th step (dataset rows); a policy does not
+                               * read them.  0: never during steps.  Default 1: every step.  Distances,
+                               * collision, reward and the observations are always current.  Rasterising
+                               * path only (the all-pairs path always refreshes). */
 } auv_option;
 #define AUV_LIDAR_RASTER 0
 #define AUV_LIDAR_ALL_PAIRS 1

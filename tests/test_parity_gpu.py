@@ -179,6 +179,38 @@ def test_generated_scenes_and_regeneration_match_oracle():
     sim.close()
 
 
+def test_metadata_refresh_interval():
+    """AUV_OPT_META_EVERY = 5: bearing, course and risk follow the oracle on every
+    fifth step and keep their values in between; everything else (state, scan,
+    distances, flags, reward, the other metadata fields) is current on every step."""
+    from gym_auv_amd import _lib
+
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=203)
+    sim = make_sim(cfg, scene)
+    env = make_oracle(cfg, scene)
+    sim.set_option(_lib.OPT_META_EVERY, 5)
+    sim.reset(scene["init_state"])
+    env.reset(scene["init_state"])
+    assert_all_equal(sim, env, "after reset")
+    acts = scenarios.random_actions(203, 12, seed=9)
+    held_meta, held_risk = env.meta.copy(), env.risk.copy()
+    for k in range(12):
+        sim.step_host(acts[k])
+        env.step(acts[k])
+        if (k + 1) % 5 == 0:
+            held_meta, held_risk = env.meta.copy(), env.risk.copy()
+        want_meta = env.meta.copy()
+        want_meta[..., 3:] = held_meta[..., 3:]
+        assert same_bits(sim.read("meta"), want_meta), k
+        assert same_bits(sim.read("risk"), held_risk), k
+        for name in ("state", "ranges", "hit", "perception", "navigation", "obst_dist", "collision", "done",
+                     "reward", "min_dist", "min_idx", "circles", "poly_pose"):
+            assert same_bits(sim.read(name), np.asarray(getattr(env, name)).reshape(sim.read(name).shape)), (name, k)
+    sim.sense()   # a sensing pass outside a step refreshes everything
+    assert same_bits(sim.read("meta"), env.meta) and same_bits(sim.read("risk"), env.risk)
+    sim.close()
+
+
 def test_masked_reset_matches_oracle():
     cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=97)
     sim = make_sim(cfg, scene)
