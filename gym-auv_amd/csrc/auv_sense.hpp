@@ -349,8 +349,9 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
     const float inv_delta = (float)R * (1.0f / 6.2831853f);
     const float half_scan = 0.5f * (float)R;
     const float margin = fmaxf(kIvMargin, kIvMarginRad * inv_delta);
-    const float inv_C = 1.0f / (float)(C > 0 ? C : 1), inv_S = 1.0f / (float)(S > 0 ? S : 1);
-    const float inv_NV = 1.0f / (float)NV, inv_O = 1.0f / (float)(O > 0 ? O : 1);
+    // reciprocals for fast_div: the 1-ulp hardware reciprocal is well within its error budget
+    const float inv_C = __builtin_amdgcn_rcpf((float)(C > 0 ? C : 1)), inv_S = __builtin_amdgcn_rcpf((float)(S > 0 ? S : 1));
+    const float inv_NV = __builtin_amdgcn_rcpf((float)NV), inv_O = __builtin_amdgcn_rcpf((float)(O > 0 ? O : 1));
 
     AUV_STAMP(0);
     // ---- phase 0: accumulators.  The pair list is filled from both ends:
