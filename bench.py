@@ -124,6 +124,9 @@ def main():
                     help="LiDAR CNN fed zero-copy with every step's scans (features head)")
     ap.add_argument("--cnn-mode", default="attached", choices=["attached", "separate"],
                     help="attached: evaluated inside the sensing kernel; separate: its own launch per step")
+    ap.add_argument("--no-auto-reset", action="store_true",
+                    help="leave finished episodes (collided / arrived / truncated envs) as they are instead of "
+                         "restarting them inside the next step, as a vectorised RL env does")
     ap.add_argument("--meta-every", type=int, default=1,
                     help="refresh the per-obstacle bearing/course/risk every n-th step only (default 1: every step)")
     ap.add_argument("--gather-scans", action="store_true",
@@ -169,6 +172,9 @@ def main():
         sim.set_option(_lib.OPT_RASTER_TILE, args.tile)
     if args.block:
         sim.set_option(_lib.OPT_SENSE_BLOCK, args.block)
+    auto_reset = not args.no_auto_reset and args.lidar_mode == 0
+    if auto_reset:
+        sim.set_option(_lib.OPT_AUTO_RESET, 1)
     if args.meta_every != 1:
         sim.set_option(_lib.OPT_META_EVERY, args.meta_every)
     sim.set_scene(scene)
@@ -300,6 +306,8 @@ def main():
                                f"{args.cnn} (features head) on every step's scans, inside k_sense" if cnn_dim
                                else "none"),
                        "meta_every": args.meta_every,
+                       "auto_reset": "finished episodes restart inside the next step, on the device" if auto_reset
+                                     else "off",
                        "sharding": f"envs x{world}, no data-path collective"},
             "kernel_ms": ({"k_vessel": vessel_s * 1e3, "k_sense": sense_s * 1e3} if fused else
                           {"k_dynamics": vessel_s * 1e3, "k_encounter": enc_s * 1e3, "k_lidar": sense_s * 1e3}),

@@ -60,18 +60,18 @@ struct VesselArgs {
 __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
     const int V = a.V;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= V) return;
+    const int lane = threadIdx.x & 63;
+    const bool live = i < V;  // no early exit: the restore loop at the end needs whole waves
+    bool restart = false;
+    if (live) {
     Vec6 s = load_state(a.state, V, i);
     int t = a.t_step[i];
-    const bool restart = a.do_step && a.auto_reset && a.done[i] != 0;
+    restart = a.do_step && a.auto_reset && a.done[i] != 0;
     if (a.do_step) {
         if (restart) {
             s = load_state(a.init, V, i);
             t = 0;
             a.episode[i] = a.episode[i] + 1;
-            for (int k = 0; k < a.C * 5; ++k) a.circles[(size_t)i * a.C * 5 + k] = a.circles0[(size_t)i * a.C * 5 + k];
-            for (int k = 0; k < a.P * 6; ++k)
-                a.poly_pose[(size_t)i * a.P * 6 + k] = a.poly_pose0[(size_t)i * a.P * 6 + k];
         } else {
             s = rkf45_step(s, a.action[i], a.action[(size_t)V + i], a.dt, a.thrust_max, a.moment_max, a.mp);
             t = t + 1;
@@ -117,7 +117,21 @@ __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
     er[ER_VOY] = voy;
     er[ER_REWARD] = rew;
     er[ER_RESET] = restart ? 1.0 : 0.0;
+    }
+    // obstacle records of the restarting envs go back to their initial values:
+    // the whole wave copies one env's records at a time (few envs restart per step)
+    unsigned long long todo = __ballot(restart);
+    const int wave_first = i - lane;
+    while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const size_t e = (size_t)(wave_first + l);
+        for (int k = lane; k < a.C * 5; k += 64) a.circles[e * a.C * 5 + k] = a.circles0[e * a.C * 5 + k];
+        for (int k = lane; k < a.P * 6; k += 64) a.poly_pose[e * a.P * 6 + k] = a.poly_pose0[e * a.P * 6 + k];
+    }
 }
+
+
 
 struct SenseArgs {
     Dims d;

@@ -1,0 +1,8 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; cd $R
+for args in "--cnn none" "--cnn none --no-auto-reset" "" "--no-auto-reset" "--cnn none --steps 1000" "--cnn none --steps 1000 --no-auto-reset"; do
+  timeout -k 10 120 python bench.py --no-cpu-baseline $args > gpurun_out/ab.log 2>&1 || { tail -5 gpurun_out/ab.log; exit 1; }
+  python -c "
+import json
+d=json.loads(open('gpurun_out/ab.log').read().strip().split('\n')[-1]); print('$args', round(d['ms_per_step'],4), {k: round(v,4) for k,v in d['kernel_ms'].items()}, d['episode_stats']['episodes_done'])"
+done
