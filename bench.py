@@ -115,7 +115,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg3_65536_moving")
+    ap.add_argument("--workload", default=None,
+                    help="default: cfg3_65536_moving on one GPU, cfg4_8x65536_moving (the same scene family, "
+                         "65,536 vessels on every GPU) on several")
     ap.add_argument("--envs", type=int, default=None, help="override vessels per GPU")
     ap.add_argument("--lidar-mode", type=int, default=0, help="0 rasterising (default), 1 all pairs")
     ap.add_argument("--tile", type=int, default=0, help="envs per k_sense workgroup, 0 = auto")
@@ -164,6 +166,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    if args.workload is None:
+        args.workload = "cfg3_65536_moving" if world == 1 else "cfg4_8x65536_moving"
     cfg, scene = scenarios.make_workload(args.workload, n_envs=args.envs, rank=rank)
     V, R, C, P, NV = cfg["n_envs"], cfg["n_rays"], cfg["n_circles"], cfg["n_polys"], cfg["n_verts"]
     sim = AuvSim(cfg, device=local_rank)
