@@ -126,6 +126,9 @@ def main():
                     help="LiDAR CNN fed zero-copy with every step's scans (features head)")
     ap.add_argument("--cnn-mode", default="attached", choices=["attached", "separate"],
                     help="attached: evaluated inside the sensing kernel; separate: its own launch per step")
+    ap.add_argument("--spin-seconds", type=float, default=1.0,
+                    help="untimed stepping that brings a cold GPU to its working clocks before the warm-up "
+                         "(0 under a profiler, so that its per-kernel averages cover the measured rollout only)")
     ap.add_argument("--no-auto-reset", action="store_true",
                     help="leave finished episodes (collided / arrived / truncated envs) as they are instead of "
                          "restarting them inside the next step, as a vectorised RL env does")
@@ -239,7 +242,7 @@ def main():
     # bring a cold GPU to its working clocks first (a fresh process on an idle
     # box runs its first second about 2x slow), then the W warm-up steps
     t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 1.0:
+    while time.perf_counter() - t_spin < args.spin_seconds:
         for k in range(50):
             sim.step_device(ptrs[k % n_act], stream=stream)
             if net is not None:

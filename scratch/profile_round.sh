@@ -4,10 +4,10 @@ tag=$1
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R; export PYTHONPATH=$R
 out=gpurun_out/prof_$tag; mkdir -p $out
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --no-cpu-baseline --steps 100 > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --no-cpu-baseline --spin-seconds 0 --steps 200 > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }
 cp $(find $out/kt -name "*kernel_stats.csv") $out/kernel_stats.csv
 run_pmc() { name=$1; shift
-  timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 2 > $out/$name.log 2>&1 || { tail -5 $out/$name.log; exit 1; }
+  timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -- python3 bench.py --no-cpu-baseline --spin-seconds 0 --steps 200 > $out/$name.log 2>&1 || { tail -5 $out/$name.log; exit 1; }
   python3 scratch/pmc_summary.py $(find $out/$name -name "*counter_collection.csv") >> $out/pmc.txt; }
 : > $out/pmc.txt
 run_pmc sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY || exit 1
