@@ -80,6 +80,82 @@ __device__ __forceinline__ int conv_layer(const float* in, int in_stride, float*
     return Lo;
 }
 
+// Between layers: the workers of one scan group either sit in one wave (a
+// wave-level LDS fence is enough) or are the whole workgroup.
+template <bool BLOCK>
+__device__ __forceinline__ void layer_sync() {
+    if (BLOCK) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The first layer of the two small networks: Conv1d(1 -> Cout, kernel 45, stride
+// 15, circular padding 15) over the 180-ray scan, i.e. 12 outputs per channel,
+// each over three consecutive 15-ray sectors.  Summation order (the same in
+// every kernel that evaluates it): one partial sum per sector, taps in order
+// from 0, then ((bias + s0) + s1) + s2.  Sector sums are independent work
+// items (stage A, into `tmp`: Cout*36 floats per scan), combined after a sync
+// (stage B, into `out`); a sector never wraps, 180 being 12 sectors.
+template <bool RELU, bool BLOCK>
+__device__ __forceinline__ void conv_sectors(const float* x, int x_stride, float* out, float* tmp, int a_stride, int ns,
+                                             const float* w, const float* b, int Cout, int worker, int n_workers) {
+    if (!BLOCK) {
+        // few lanes per scan: each keeps the three sector sums of its outputs in
+        // registers (same order of operations, no staging)
+        for (int idx = worker; idx < ns * Cout * 12; idx += n_workers) {
+            const int s = idx / (Cout * 12);
+            const int col = idx - s * (Cout * 12);
+            const int co = col / 12;
+            const int lo = col - co * 12;
+            float part[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                int sec = lo - 1 + j;
+                sec = sec < 0 ? sec + 12 : (sec >= 12 ? sec - 12 : sec);
+                const float* wr = w + co * 45 + j * 15;
+                const float* xr = x + (size_t)s * x_stride + sec * 15;
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 15; ++k) acc += wr[k] * xr[k];
+                part[j] = acc;
+            }
+            float acc = ((b[co] + part[0]) + part[1]) + part[2];
+            if (RELU) acc = acc > 0.f ? acc : 0.f;
+            out[(size_t)s * a_stride + col] = acc;
+        }
+        return;
+    }
+    const int per_scan = Cout * 36;
+    for (int idx = worker; idx < ns * per_scan; idx += n_workers) {
+        const int s = idx / per_scan;
+        const int el = idx - s * per_scan;  // (co * 12 + lo) * 3 + part
+        const int col = el / 3;
+        const int part = el - col * 3;
+        const int co = col / 12;
+        const int lo = col - co * 12;
+        int sec = lo - 1 + part;  // sector of the scan under this third of the kernel
+        sec = sec < 0 ? sec + 12 : (sec >= 12 ? sec - 12 : sec);
+        const float* wr = w + co * 45 + part * 15;
+        const float* xr = x + (size_t)s * x_stride + sec * 15;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) acc += wr[k] * xr[k];
+        tmp[(size_t)s * a_stride + el] = acc;
+    }
+    layer_sync<BLOCK>();
+    for (int idx = worker; idx < ns * Cout * 12; idx += n_workers) {
+        const int s = idx / (Cout * 12);
+        const int col = idx - s * (Cout * 12);
+        const float* t = tmp + (size_t)s * a_stride + col * 3;
+        float acc = ((b[col / 12] + t[0]) + t[1]) + t[2];
+        if (RELU) acc = acc > 0.f ? acc : 0.f;
+        out[(size_t)s * a_stride + col] = acc;
+    }
+}
+
 template <bool RELU>
 __device__ __forceinline__ void linear_layer(const float* in, int in_stride, float* out, int out_stride, int ns,
                                              const float* w, const float* b, int n_in, int n_out, int worker,
@@ -97,26 +173,16 @@ __device__ __forceinline__ void linear_layer(const float* in, int in_stride, flo
     }
 }
 
-// Between layers: the workers of one scan group either sit in one wave (a
-// wave-level LDS fence is enough) or are the whole workgroup.
-template <bool BLOCK>
-__device__ __forceinline__ void layer_sync() {
-    if (BLOCK) {
-        __syncthreads();
-    } else {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// LDS floats per activation buffer of one scan (two buffers are needed)
-__host__ __device__ inline int cnn_buf_floats(int kind) { return kind == CNN_DEEP ? kCnnBuf : 40; }
+// LDS floats of the two activation buffers p and q of one scan (q directly behind p)
+__host__ __device__ inline int cnn_p_floats(int kind) { return kind == CNN_DEEP ? kCnnBuf : 40; }
+__host__ __device__ inline int cnn_q_floats(int kind) { return kind == CNN_DEEP ? kCnnBuf : 112; }  // 3 * 36 sector sums
+__host__ __device__ inline int cnn_act_floats(int kind) { return cnn_p_floats(kind) + cnn_q_floats(kind); }
 // the two small networks can run inside the sensing kernel, weights staged in LDS
 __host__ __device__ inline bool cnn_fits_sense_kernel(int kind) { return kind == CNN_SHALLOW || kind == CNN_2DEEP; }
 
 // Forward pass of `ns` scans by `n_workers` cooperating threads.  Scan s has
 // its 180 closeness values at x + s*x_stride and two activation buffers of
-// cnn_buf_floats(kind) floats at p + s*a_stride and q + s*a_stride (all LDS);
+// cnn_p_floats / cnn_q_floats(kind) floats at p + s*a_stride and q + s*a_stride (all LDS);
 // its row of the result goes to out + s*out_dim (global).  BLOCK: the workers
 // are the whole workgroup (all of its threads must call), else lanes of one
 // wave.  WITH_DEEP = false leaves the largest network out of the instantiation
@@ -133,11 +199,11 @@ __device__ __forceinline__ void cnn_forward(const float* x, int x_stride, float*
     if (kind == CNN_SHALLOW) {
         // w: conv.weight[45] conv.bias[1] linear.weight[12] linear.bias[1]
         if (head == HEAD_FEATURES) {
-            AUV_CONV(false, false, x, x_stride, p, w, w + 45, 1, 1, kCnnLen, 45, 15, 15);
+            conv_sectors<false, BLOCK>(x, x_stride, p, q, a_stride, ns, w, w + 45, 1, worker, n_workers);
             res = p;
             n_res = 12;
         } else {
-            AUV_CONV(true, false, x, x_stride, p, w, w + 45, 1, 1, kCnnLen, 45, 15, 15);
+            conv_sectors<true, BLOCK>(x, x_stride, p, q, a_stride, ns, w, w + 45, 1, worker, n_workers);
             layer_sync<BLOCK>();
             AUV_LIN(true, p, q, w + 46, w + 58, 12, 1);
             res = q;
@@ -145,7 +211,7 @@ __device__ __forceinline__ void cnn_forward(const float* x, int x_stride, float*
         }
     } else if (!WITH_DEEP || kind == CNN_2DEEP) {
         // w: c1.w[3*45] c1.b[3] c2.w[2*3*3] c2.b[2] c3.w[1*2*3] c3.b[1] lin.w[12] lin.b[1]
-        AUV_CONV(true, false, x, x_stride, p, w, w + 135, 1, 3, kCnnLen, 45, 15, 15);
+        conv_sectors<true, BLOCK>(x, x_stride, p, q, a_stride, ns, w, w + 135, 3, worker, n_workers);
         layer_sync<BLOCK>();
         AUV_CONV(true, false, p, a_stride, q, w + 138, w + 156, 3, 2, 12, 3, 1, 1);
         layer_sync<BLOCK>();
@@ -200,14 +266,14 @@ __device__ __forceinline__ void cnn_forward(const float* x, int x_stride, float*
 
 // dynamic LDS of one k_cnn workgroup: the scans, then two activation buffers per scan
 __host__ __device__ inline size_t cnn_lds_bytes(int kind) {
-    return (size_t)kCnnScans * (kCnnBuf + 2 * cnn_buf_floats(kind)) * sizeof(float);
+    return (size_t)kCnnScans * (kCnnBuf + 2 * cnn_p_floats(kind)) * sizeof(float);  // no sector staging here
 }
 
 __global__ __launch_bounds__(256) void k_cnn(CnnArgs a) {
     extern __shared__ __align__(16) float cnn_lds[];
-    const int nb = cnn_buf_floats(a.kind);
+    const int na = 2 * cnn_p_floats(a.kind);
     float* xs = cnn_lds;                       // [kCnnScans][kCnnBuf], rows 16-B aligned
-    float* act = cnn_lds + kCnnScans * kCnnBuf;  // [kCnnScans][2][nb]
+    float* act = cnn_lds + kCnnScans * kCnnBuf;  // [kCnnScans][na]: p then q
     const int tid = threadIdx.x;
     const long long s0 = (long long)blockIdx.x * kCnnScans;
     const int ns = (int)((a.B - s0) < kCnnScans ? (a.B - s0) : kCnnScans);
@@ -224,7 +290,8 @@ __global__ __launch_bounds__(256) void k_cnn(CnnArgs a) {
     const int s = tid / kCnnLanes;
     const int lane = tid - s * kCnnLanes;
     if (s >= ns) return;
-    cnn_forward<true, false>(xs + s * kCnnBuf, 0, act + (size_t)s * 2 * nb, act + ((size_t)s * 2 + 1) * nb, 0, 1, a.w,
+    cnn_forward<true, false>(xs + s * kCnnBuf, 0, act + (size_t)s * na, act + (size_t)s * na + cnn_p_floats(a.kind), 0, 1,
+                             a.w,
                              a.out + (s0 + s) * cnn_out_dim(a.kind, a.head), a.kind, a.head, lane, kCnnLanes);
 }
 

@@ -186,7 +186,7 @@ struct SenseLayout {
 // activation buffers per env reuse the bytes in front of best[], which are
 // dead by then; the front is padded when it is smaller than that.
 __host__ __device__ inline size_t sense_cnn_bytes(int TE, int cnn_kind) {
-    return cnn_kind < 0 ? 0 : ((size_t)((cnn_n_weights(cnn_kind) + 3) & ~3) + (size_t)TE * 2 * cnn_buf_floats(cnn_kind)) * 4;
+    return cnn_kind < 0 ? 0 : ((size_t)((cnn_n_weights(cnn_kind) + 3) & ~3) + (size_t)TE * cnn_act_floats(cnn_kind)) * 4;
 }
 __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P, int NV, int cap, int cnn_kind) {
     SenseLayout L;
@@ -772,9 +772,9 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
         __syncthreads();
         // the tile's scans together, output elements dealt over the workgroup;
         // each is summed by one thread in the order k_cnn uses: same values
-        const int nb = cnn_buf_floats(a.cnn_kind);
         float* act = cnn_lds + ((n_w + 3) & ~3);
-        cnn_forward<false, true>(reinterpret_cast<const float*>(ids), R, act, act + nb, 2 * nb, ne, cnn_lds,
+        cnn_forward<false, true>(reinterpret_cast<const float*>(ids), R, act, act + cnn_p_floats(a.cnn_kind),
+                                 cnn_act_floats(a.cnn_kind), ne, cnn_lds,
                                  a.cnn_out + (size_t)e0 * cnn_out_dim(a.cnn_kind, a.cnn_head), a.cnn_kind,
                                  a.cnn_head, tid, nthr);
     }
