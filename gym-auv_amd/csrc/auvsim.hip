@@ -18,6 +18,7 @@
 #include "auv_sense.hpp"
 #include "auv_cnn.hpp"
 #include "auv_scenegen.hpp"
+#include "auv_format.hpp"
 
 using namespace auv;
 
@@ -929,16 +930,35 @@ int auv_debug_set_stamps(void* p) {
 int64_t auv_format_rows(const double* values, const int32_t* row_len, int64_t n_rows, int64_t stride, char* out,
                         int64_t out_cap) {
     if (!values || !row_len || !out || n_rows < 0 || stride < 0) return AUV_ERR_ARG;
-    int64_t pos = 0;
+    // upper bound of the text: 26 bytes per value + separator, 1 per row
+    std::vector<int64_t> need((size_t)n_rows + 1, 0);
     for (int64_t i = 0; i < n_rows; ++i) {
-        const double* row = values + i * stride;
-        for (int32_t j = 0; j < row_len[i]; ++j) {
-            if (out_cap - pos < 32) return AUV_ERR_MEMORY;
-            if (j) out[pos++] = ' ';
-            pos += snprintf(out + pos, 30, "%.18e", row[j]);
-        }
-        if (out_cap - pos < 2) return AUV_ERR_MEMORY;
-        out[pos++] = '\n';
+        if (row_len[i] < 0 || row_len[i] > stride) return AUV_ERR_ARG;
+        need[(size_t)i + 1] = need[(size_t)i] + (int64_t)row_len[i] * 27 + 1;
+    }
+    if (need[(size_t)n_rows] > out_cap) return AUV_ERR_MEMORY;
+    // blocks of rows on the host threads, each into its worst-case slot of
+    // `out`, then closed up in order
+    int n_thr = (int)std::thread::hardware_concurrency();
+    if (n_thr > 16) n_thr = 16;
+    if (n_thr < 1 || need[(size_t)n_rows] < (1 << 20)) n_thr = 1;
+    std::vector<int64_t> got((size_t)n_thr, 0), first((size_t)n_thr + 1, 0);
+    for (int t = 0; t <= n_thr; ++t) first[(size_t)t] = n_rows * t / n_thr;
+    auto work = [&](int t) {
+        got[(size_t)t] = auvfmt::format_block(values, row_len, stride, first[(size_t)t], first[(size_t)t + 1],
+                                              out + need[(size_t)first[(size_t)t]]);
+    };
+    if (n_thr == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_thr; ++t) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
+    int64_t pos = got[0];
+    for (int t = 1; t < n_thr; ++t) {
+        memmove(out + pos, out + need[(size_t)first[(size_t)t]], (size_t)got[(size_t)t]);
+        pos += got[(size_t)t];
     }
     return pos;
 }

@@ -28,9 +28,10 @@ SENSOR_RANGE = 150.0  # utils/dataloader.py:56
 # ----------------------------------------------------------------------------
 # writing
 # ----------------------------------------------------------------------------
-def format_rows(values: np.ndarray, row_len=None) -> bytes:
+def format_rows(values: np.ndarray, row_len=None, view: bool = False):
     """Text of ragged rows: row i = values[i, :row_len[i]] (all columns when
-    row_len is None).  Formatting runs in the native library."""
+    row_len is None), as bytes (or, with view=True, as a uint8 array without the
+    copy).  Formatting runs in the native library, on the host threads."""
     lib = _lib.load()
     values = np.ascontiguousarray(values, dtype=np.float64)
     if values.ndim != 2:
@@ -42,12 +43,12 @@ def format_rows(values: np.ndarray, row_len=None) -> bytes:
     if row_len.shape != (n,) or (row_len > stride).any() or (row_len < 0).any():
         raise ValueError("row_len")
     cap = int(row_len.sum()) * 27 + n + 64
-    buf = C.create_string_buffer(cap)
+    buf = np.empty(cap, dtype=np.uint8)
     got = lib.auv_format_rows(values.ctypes.data_as(C.c_void_p), row_len.ctypes.data_as(C.c_void_p), n, stride,
-                              buf, cap)
+                              buf.ctypes.data_as(C.c_void_p), cap)
     if got < 0:
         raise _lib.AuvError(int(got), "auv_format_rows")
-    return buf.raw[:got]
+    return buf[:got] if view else buf[:got].tobytes()
 
 
 class DatasetWriter:
@@ -74,9 +75,9 @@ class DatasetWriter:
         order = np.argsort(~tracked, axis=1, kind="stable")
         risk_c = np.take_along_axis(risk, order, axis=1)
         meta_c = np.take_along_axis(meta, order[:, :, None], axis=1).reshape(n, O * 5)
-        self._f["LiDAR"].write(format_rows(ranges))
-        self._f["risk"].write(format_rows(risk_c, cnt))
-        self._f["metadata"].write(format_rows(np.concatenate([own, meta_c], axis=1), 2 + 5 * cnt))
+        self._f["LiDAR"].write(format_rows(ranges, view=True))
+        self._f["risk"].write(format_rows(risk_c, cnt, view=True))
+        self._f["metadata"].write(format_rows(np.concatenate([own, meta_c], axis=1), 2 + 5 * cnt, view=True))
         self.rows += n
         return n
 

@@ -86,3 +86,26 @@ def test_writer_round_trip(tmp_path):
     out = D.load_lidar_dataset(w.paths["LiDAR"], w.paths["risk"], mode="max")
     assert out["train"][0].shape[1:] == (1, 180) and out["train"][0].dtype == np.float32
     assert np.allclose(out["test"][0][-1, 0], 1 - ranges[keep][-1] / 150, atol=1e-7)
+
+
+def test_native_formatter_is_printf_exact():
+    """The native "%.18e" formatter builds the 19 digits itself (exact 128-bit
+    arithmetic, round half even) for 1e-9 <= |v| < 1e19 and defers to printf
+    elsewhere: its bytes must be printf's for magnitudes on both sides of every
+    boundary, ties, powers of ten and two, signed zeros, denormals, infinities."""
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([
+        rng.uniform(0, 150, 20000), rng.uniform(-3.2, 3.2, 20000),
+        10.0 ** rng.uniform(-12, 21, 20000) * rng.choice([-1, 1], 20000),
+        np.ldexp(rng.integers(1, 2 ** 53, 20000).astype(float), rng.integers(-90, 12, 20000)),
+        10.0 ** np.arange(-12, 22), np.nextafter(10.0 ** np.arange(-12, 22), 0), 2.0 ** np.arange(-40, 64),
+        [0.0, -0.0, 0.5, 0.1, 0.2, 150.0, 1e-300, 5e-324, 1.7976931348623157e308, np.inf, -np.inf,
+         0.30000000000000004, 999999999999999999.0, 1 - 2 ** -53, 2 ** 60 + 2 ** 8, 1.5, 2.5, 0.125]])
+    n = len(vals) // 4 * 4
+    v = vals[:n].reshape(-1, 4)
+    want = "".join(" ".join("%.18e" % x for x in row) + "\n" for row in v).encode()
+    assert D.format_rows(v) == want
+    # large inputs take the multi-threaded path: same bytes as row-by-row formatting
+    big = rng.uniform(0, 150, (3000, 180))
+    one = D.format_rows(big)
+    assert one == b"".join(D.format_rows(big[i:i + 1]) for i in range(0, 3000, 1)) and len(one) > (1 << 20)
