@@ -350,6 +350,55 @@ def test_full_size_batch_every_env_against_c_oracle(name, steps, mode):
     sim.close()
 
 
+SHAPES = [
+    # V, R, C, P, NV, n_sides, tile, block
+    (1, 1, 1, 1, 3, 3, 0, 0),
+    (5, 7, 0, 2, 5, None, 0, 64),
+    (67, 33, 3, 0, 5, None, 3, 128),
+    (67, 180, 16, 5, 16, 16, 0, 0),
+    (130, 1000, 2, 3, 7, 7, 1, 512),
+    (130, 180, 5, 6, 5, None, 16, 256),
+    (259, 90, 7, 1, 4, 4, 5, 0),
+    (31, 360, 0, 9, 8, 6, 2, 512),
+    (1000, 64, 1, 1, 3, 3, 64, 64),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"V{s[0]}R{s[1]}C{s[2]}P{s[3]}NV{s[4]}t{s[6]}b{s[7]}" for s in SHAPES])
+def test_odd_shapes_tiles_and_workgroup_sizes(shape):
+    """Shapes off the benchmark grid (one ray, prime counts, no circles / no
+    polygons, 16-vertex hulls with fewer sides in use, obstacle counts that are
+    not powers of two, scans of 1,000 rays) under forced tile and workgroup
+    sizes, with tight scenes so that vessels end up inside obstacles: every
+    buffer against the C oracle, rasterising kernel, after reset and 6 steps."""
+    from gym_auv_amd import _lib
+    from oracle import c_oracle
+
+    V, R, C, P, NV, n_sides, tile, block = shape
+    cfg = params.make_config(V, C, P, NV, n_rays=R, max_steps=4)
+    scene = scenarios.make_scene(V, C, P, NV, seed=V + R, extent=70.0, n_sides=n_sides, width=(6.0, 30.0))
+    sim = make_sim(cfg, scene)
+    if tile:
+        sim.set_option(_lib.OPT_RASTER_TILE, tile)
+    if block:
+        sim.set_option(_lib.OPT_SENSE_BLOCK, block)
+    env = c_oracle.COracleEnv(cfg, params.ray_table(R))
+    env.set_scene(scene["circles"], scene["poly_pose"], scene["poly_verts"], scene["poly_nv"], scene["poly_heading"])
+    env.set_path(scene["path"])
+    env.episode = np.zeros(V, dtype=np.int32)
+    sim.reset(scene["init_state"])
+    env.reset(scene["init_state"])
+    assert_all_equal(sim, env, "after reset")
+    acts = scenarios.random_actions(V, 6, seed=R)
+    acts[:, 0] = 1.0
+    for k in range(6):
+        sim.step_host(acts[k])
+        env.step(acts[k])
+        assert_all_equal(sim, env, f"after step {k + 1}")
+    env.close()
+    sim.close()
+
+
 def test_device_action_pointer_and_dlpack_views():
     import torch
 
