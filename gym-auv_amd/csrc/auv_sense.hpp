@@ -60,13 +60,37 @@ struct VesselArgs {
 __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
     const int V = a.V;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool live = i < V;  // no early exit: the restore loop at the end needs whole waves
-    bool restart = false;
+    const bool live = i < V;  // no early exit: the whole workgroup takes part in the restore below
+    // Envs that restart get their obstacle records back from the initial ones.
+    // The workgroup shares that copy, and its loads are issued here, before the
+    // integration, whose ~8 us hide their latency; the stores follow at the end.
+    __shared__ int rs_env[256];
+    __shared__ int rs_n;
+    if (threadIdx.x == 0) rs_n = 0;
+    __syncthreads();
+    bool restart = live && a.do_step && a.auto_reset && a.done[i] != 0;
+    if (restart) rs_env[atomicAdd(&rs_n, 1)] = i;
+    __syncthreads();
+    const int n_el = a.C * 5, n_rec = a.C * 5 + a.P * 6;  // doubles per env: circles, then polygon poses
+    const int n_items = rs_n * n_rec;
+    auto item_src = [&](int item) -> const double* {
+        const int r = item / n_rec, k = item - r * n_rec;
+        const size_t e = (size_t)rs_env[r];
+        return k < n_el ? a.circles0 + e * n_el + k : a.poly_pose0 + e * (n_rec - n_el) + (k - n_el);
+    };
+    auto item_dst = [&](int item) -> double* {
+        const int r = item / n_rec, k = item - r * n_rec;
+        const size_t e = (size_t)rs_env[r];
+        return k < n_el ? a.circles + e * n_el + k : a.poly_pose + e * (n_rec - n_el) + (k - n_el);
+    };
+    const int nthr = blockDim.x;
+    double held[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((int)threadIdx.x + j * nthr < n_items) held[j] = *item_src(threadIdx.x + j * nthr);
     if (live) {
     Vec6 s = load_state(a.state, V, i);
     int t = a.t_step[i];
-    restart = a.do_step && a.auto_reset && a.done[i] != 0;
     if (a.do_step) {
         if (restart) {
             s = load_state(a.init, V, i);
@@ -118,20 +142,11 @@ __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
     er[ER_REWARD] = rew;
     er[ER_RESET] = restart ? 1.0 : 0.0;
     }
-    // obstacle records of the restarting envs go back to their initial values:
-    // the whole wave copies one env's records at a time (few envs restart per step)
-    unsigned long long todo = __ballot(restart);
-    const int wave_first = i - lane;
-    while (todo) {
-        const int l = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const size_t e = (size_t)(wave_first + l);
-        for (int k = lane; k < a.C * 5; k += 64) a.circles[e * a.C * 5 + k] = a.circles0[e * a.C * 5 + k];
-        for (int k = lane; k < a.P * 6; k += 64) a.poly_pose[e * a.P * 6 + k] = a.poly_pose0[e * a.P * 6 + k];
-    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((int)threadIdx.x + j * nthr < n_items) *item_dst(threadIdx.x + j * nthr) = held[j];
+    for (int item = threadIdx.x + 4 * nthr; item < n_items; item += nthr) *item_dst(item) = *item_src(item);
 }
-
-
 
 struct SenseArgs {
     Dims d;

@@ -73,6 +73,7 @@ struct auv_sim {
     int lidar_mode = AUV_LIDAR_RASTER;
     int raster_te = 1, raster_cap = 2048, sense_block = 256;
     int raster_want = 0;  // envs per workgroup asked for (0 = automatic)
+    int block_want = 0;   // threads per workgroup asked for (0 = automatic)
     int auto_reset = 0;   // done envs restart inside the next step
     int regenerate = 0;   // ... with a newly generated scene
     int meta_every = 1;   // steps between refreshes of bearing / course / risk (0: only outside steps)
@@ -175,6 +176,8 @@ void set_raster_tile(auv_sim* h, int want) {
     h->raster_te = te;
     h->raster_cap = cap;
     h->raster_lds = sense_layout(te, d.R, d.C, d.P, d.NV, cap, cf).total;
+    // a tile with many primitives (dense scenes) keeps 8 waves busy; the usual one is best with 4
+    h->sense_block = h->block_want ? h->block_want : ((long long)te * (d.C + S) >= 768 ? 512 : 256);
     // the pair list packs (primitive, ray offset) into 16 bits each
     if ((long long)te * (d.C + S) > 65535 || d.R > 65535) h->raster_lds = (size_t)1 << 30;
 }
@@ -861,6 +864,7 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
         case AUV_OPT_SENSE_BLOCK:
             if (value != 64 && value != 128 && value != 256 && value != 512)
                 return fail(h, AUV_ERR_ARG, "auv_set_option: k_sense workgroup size must be 64, 128, 256 or 512");
+            h->block_want = value;
             h->sense_block = value;
             return AUV_OK;
         case AUV_OPT_AUTO_RESET:
