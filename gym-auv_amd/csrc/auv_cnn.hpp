@@ -295,4 +295,132 @@ __global__ __launch_bounds__(256) void k_cnn(CnnArgs a) {
                              a.out + (s0 + s) * cnn_out_dim(a.kind, a.head), a.kind, a.head, lane, kCnnLanes);
 }
 
+// ---- the deep network, its own kernel -------------------------------------
+// models/lidar_cnn_deep.py:19-96 with channels [2,4,4,6], kernel 9, circular
+// padding 4, ReLU + MaxPool1d(2, ceil) after every convolution, then
+// Linear(72,40)+ReLU, Linear(40,8) [features], ReLU + Linear(8,1)+ReLU [risk].
+// 16 lanes per scan as in k_cnn, but: every shape is a compile-time constant;
+// activation rows carry their circular halo (4 left, 5 right), so a tap is one
+// LDS read at a fixed offset; a lane owns pooled position lo, reads its 10-wide
+// input window once and runs all output channels over it with the weights in
+// scalar registers (the channel loop is wave-uniform); the two linear layers
+// read transposed weights from LDS (lane = output, no bank conflicts).
+// Accumulation order is that of conv_layer / linear_layer; products and sums
+// are fused (fmaf), which only tightens the result (tolerance-compared).
+constexpr int kDeepHaloL = 4, kDeepHaloR = 5;
+constexpr int kDeepRowA = 216;  // floats per scan of buffer A: max(180+9, 4*(45+9), 72)
+constexpr int kDeepRowB = 200;  // buffer B: max(2*(90+9), 4*(23+9), 40)
+constexpr int kDeepL1T = 72 * 40, kDeepL2T = 40 * 8;
+
+__host__ __device__ inline size_t cnn_deep_lds_bytes() {
+    return ((size_t)kCnnScans * (kDeepRowA + kDeepRowB) + kDeepL1T + kDeepL2T) * sizeof(float);
+}
+
+// store v as logical element lo of a row of length Lo that carries halos
+__device__ __forceinline__ void put_with_halo(float* row, int Lo, int lo, float v) {
+    row[kDeepHaloL + lo] = v;
+    if (lo >= Lo - kDeepHaloL) row[lo - (Lo - kDeepHaloL)] = v;
+    if (lo < kDeepHaloR) row[kDeepHaloL + Lo + lo] = v;
+}
+
+template <int CIN, int COUT, int L, bool LAST>
+__device__ __forceinline__ void deep_conv(const float* in, float* out, const float* w, const float* b, int lane) {
+    constexpr int Lo = (L + 1) / 2;
+    constexpr int LsI = L + kDeepHaloL + kDeepHaloR;
+    constexpr int LsO = LAST ? Lo : Lo + kDeepHaloL + kDeepHaloR;
+    for (int lo = lane; lo < Lo; lo += kCnnLanes) {
+        float x[CIN][10];  // inputs 2lo-4 .. 2lo+5 of every channel
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int j = 0; j < 10; ++j) x[ci][j] = in[ci * LsI + 2 * lo + j];
+        const bool two = 2 * lo + 1 < L;  // the last pooled cell of an odd row covers one position
+#pragma nounroll
+        for (int co = 0; co < COUT; ++co) {  // wave-uniform: weights come through the scalar unit
+            float a0 = b[co], a1 = b[co];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const float wv = w[(co * CIN + ci) * 9 + k];
+                    a0 = __builtin_fmaf(wv, x[ci][k], a0);
+                    a1 = __builtin_fmaf(wv, x[ci][k + 1], a1);
+                }
+            a0 = a0 > 0.f ? a0 : 0.f;
+            a1 = a1 > 0.f ? a1 : 0.f;
+            const float v = (two && a1 > a0) ? a1 : a0;
+            if (LAST) out[co * LsO + lo] = v;
+            else put_with_halo(out + co * LsO, Lo, lo, v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cnn_deep(CnnArgs a) {
+    extern __shared__ __align__(16) float cnn_lds[];
+    float* bufA = cnn_lds;                                   // [kCnnScans][kDeepRowA]
+    float* bufB = bufA + kCnnScans * kDeepRowA;               // [kCnnScans][kDeepRowB]
+    float* w1t = bufB + kCnnScans * kDeepRowB;                // [72][40] = linear_1.0.weight transposed
+    float* w2t = w1t + kDeepL1T;                              // [40][8]  = linear_1.2.weight transposed
+    const int tid = threadIdx.x;
+    const long long s0 = (long long)blockIdx.x * kCnnScans;
+    const int ns = (int)((a.B - s0) < kCnnScans ? (a.B - s0) : kCnnScans);
+    const float* w = a.w;
+    // packed order: c1.w[18] b[2] c2.w[72] b[4] c3.w[144] b[4] c4.w[216] b[6] l1.w[2880] b[40] l2.w[320] b[8] l3.w[8] b[1]
+    for (int i = tid; i < kDeepL1T; i += 256) {
+        const int o = i / 72, k = i - o * 72;
+        w1t[k * 40 + o] = w[466 + i];
+    }
+    for (int i = tid; i < kDeepL2T; i += 256) {
+        const int o = i / 40, k = i - o * 40;
+        w2t[k * 8 + o] = w[3386 + i];
+    }
+    // the tile's scans, each into a row with its circular halo
+    for (int i = tid; i < ns * kCnnLen; i += 256) {
+        const int s = i / kCnnLen, f = i - s * kCnnLen;
+        put_with_halo(bufA + s * kDeepRowA, kCnnLen, f, a.scans[s0 * kCnnLen + i]);
+    }
+    __syncthreads();
+    const int s = tid / kCnnLanes;
+    const int lane = tid - s * kCnnLanes;
+    if (s >= ns) return;
+    float* A = bufA + s * kDeepRowA;
+    float* B = bufB + s * kDeepRowB;
+    deep_conv<1, 2, 180, false>(A, B, w, w + 18, lane);         // 2 x 90
+    layer_sync<false>();
+    deep_conv<2, 4, 90, false>(B, A, w + 20, w + 92, lane);     // 4 x 45
+    layer_sync<false>();
+    deep_conv<4, 4, 45, false>(A, B, w + 96, w + 240, lane);    // 4 x 23
+    layer_sync<false>();
+    deep_conv<4, 6, 23, true>(B, A, w + 244, w + 460, lane);    // 6 x 12, plain rows = the 72 inputs of linear 1
+    layer_sync<false>();
+    for (int o = lane; o < 40; o += kCnnLanes) {
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 72; ++k) acc = __builtin_fmaf(A[k], w1t[k * 40 + o], acc);
+        acc += w[3346 + o];
+        B[o] = acc > 0.f ? acc : 0.f;
+    }
+    layer_sync<false>();
+    float feat = 0.f;
+    if (lane < 8) {
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 40; ++k) acc = __builtin_fmaf(B[k], w2t[k * 8 + lane], acc);
+        feat = acc + w[3706 + lane];
+    }
+    float* out = a.out + (s0 + s) * cnn_out_dim(CNN_DEEP, a.head);
+    if (a.head == HEAD_FEATURES) {
+        if (lane < 8) out[lane] = feat;
+        return;
+    }
+    if (lane < 8) A[lane] = feat > 0.f ? feat : 0.f;
+    layer_sync<false>();
+    if (lane == 0) {
+        float acc = 0.f;
+        for (int k = 0; k < 8; ++k) acc = __builtin_fmaf(A[k], w[3714 + k], acc);
+        acc += w[3722];
+        out[0] = acc > 0.f ? acc : 0.f;
+    }
+}
+
 }  // namespace auv

@@ -249,8 +249,12 @@ int launch_cnn(auv_sim* h, hipStream_t st) {
     ca.B = h->d.V;
     ca.kind = h->cnn_kind;
     ca.head = h->cnn_head;
-    hipLaunchKernelGGL(k_cnn, dim3((unsigned)((h->d.V + kCnnScans - 1) / kCnnScans)), dim3(256),
-                       cnn_lds_bytes(ca.kind), st, ca);
+    if (ca.kind == CNN_DEEP)
+        hipLaunchKernelGGL(k_cnn_deep, dim3((unsigned)((h->d.V + kCnnScans - 1) / kCnnScans)), dim3(256),
+                           cnn_deep_lds_bytes(), st, ca);
+    else
+        hipLaunchKernelGGL(k_cnn, dim3((unsigned)((h->d.V + kCnnScans - 1) / kCnnScans)), dim3(256),
+                           cnn_lds_bytes(ca.kind), st, ca);
     HIP_TRY(h, hipGetLastError());
     return AUV_OK;
 }
@@ -1054,7 +1058,10 @@ int auv_cnn_forward(auv_cnn_handle c, const float* scans, int64_t n_scans, int32
     const unsigned blocks = (unsigned)((n_scans + kCnnScans - 1) / kCnnScans);
     if ((reinterpret_cast<uintptr_t>(scans) & 15u) != 0)
         return cnn_fail(c, AUV_ERR_ARG, "auv_cnn_forward: scans must be 16-byte aligned");
-    hipLaunchKernelGGL(k_cnn, dim3(blocks), dim3(256), cnn_lds_bytes(a.kind), (hipStream_t)stream, a);
+    if (a.kind == CNN_DEEP)
+        hipLaunchKernelGGL(k_cnn_deep, dim3(blocks), dim3(256), cnn_deep_lds_bytes(), (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(k_cnn, dim3(blocks), dim3(256), cnn_lds_bytes(a.kind), (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cnn_fail(c, AUV_ERR_DEVICE, "k_cnn launch failed: %s", hipGetErrorString(e));
     return AUV_OK;
