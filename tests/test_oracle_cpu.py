@@ -184,3 +184,34 @@ def test_masked_reset_restores_obstacles():
     assert np.array_equal(env.poly_pose[[0, 3]], p0[[0, 3]])
     assert not np.array_equal(env.poly_pose[1], p0[1])
     assert list(env.t_step) == [0, 3, 3, 0]
+
+
+def test_oracles_reproduce_the_committed_regression_vectors():
+    """tests/golden/sim_golden.npz (made by make_sim_golden.py from the numpy
+    oracle; not reference data) pins the arithmetic contract itself: both oracles
+    must still produce those bits."""
+    import os
+
+    from gym_auv_amd import params
+    from oracle import c_oracle
+    from tests.helpers import PAIRS, make_oracle, same_bits
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sim_golden.npz"))
+    scene = {k[len("scene_"):]: g[k] for k in g.files if k.startswith("scene_")}
+    V = scene["path"].shape[0]
+    cfg = params.make_config(V, scene["circles"].shape[1], scene["poly_pose"].shape[1], scene["poly_verts"].shape[2])
+    env = make_oracle(cfg, scene)
+    cenv = c_oracle.COracleEnv(cfg, params.ray_table(cfg["n_rays"]))
+    cenv.set_scene(scene["circles"], scene["poly_pose"], scene["poly_verts"], scene["poly_nv"], scene["poly_heading"])
+    cenv.set_path(scene["path"])
+    cenv.episode = np.zeros(V, dtype=np.int32)
+    for e in (env, cenv):
+        e.reset(scene["init_state"])
+        assert same_bits(e.ranges, g["reset_ranges"]) and same_bits(e.hit, g["reset_hit"])
+        for k in range(g["actions"].shape[0]):
+            e.step(g["actions"][k])
+            assert same_bits(e.ranges, g[f"ranges_{k}"]) and same_bits(e.hit, g[f"hit_{k}"])
+            assert same_bits(e.state, g[f"state_{k}"])
+        for name, attr in PAIRS.items():
+            want = g[f"final_{name}"]
+            assert same_bits(np.asarray(getattr(e, attr)).reshape(want.shape), want), name

@@ -14,7 +14,7 @@ import pytest
 from gym_auv_amd import params, scenarios
 from gym_auv_amd.sim import AuvSim
 from oracle import auv_oracle as O
-from tests.helpers import assert_all_equal, make_oracle, make_sim, same_bits
+from tests.helpers import PAIRS, assert_all_equal, make_oracle, make_sim, same_bits
 
 pytestmark = pytest.mark.gpu
 
@@ -396,6 +396,30 @@ def test_odd_shapes_tiles_and_workgroup_sizes(shape):
         env.step(acts[k])
         assert_all_equal(sim, env, f"after step {k + 1}")
     env.close()
+    sim.close()
+
+
+@MODES
+def test_device_reproduces_the_committed_regression_vectors(mode):
+    """tests/golden/sim_golden.npz: vectors made by the numpy oracle (not
+    reference data; they pin the build's own arithmetic contract).  The device
+    must produce them without any oracle in the loop."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sim_golden.npz"))
+    scene = {k[len("scene_"):]: g[k] for k in g.files if k.startswith("scene_")}
+    V = scene["path"].shape[0]
+    cfg = params.make_config(V, scene["circles"].shape[1], scene["poly_pose"].shape[1], scene["poly_verts"].shape[2])
+    sim = make_sim(cfg, scene, lidar_mode=mode)
+    sim.reset(scene["init_state"])
+    assert same_bits(sim.read("ranges"), g["reset_ranges"]) and same_bits(sim.read("hit"), g["reset_hit"])
+    for k in range(g["actions"].shape[0]):
+        sim.step_host(g["actions"][k])
+        assert same_bits(sim.read("ranges"), g[f"ranges_{k}"]) and same_bits(sim.read("hit"), g[f"hit_{k}"])
+        assert same_bits(sim.read("state"), g[f"state_{k}"])
+    for name in PAIRS:
+        want = g[f"final_{name}"]
+        assert same_bits(sim.read(name), want.reshape(sim.read(name).shape)), name
     sim.close()
 
 
