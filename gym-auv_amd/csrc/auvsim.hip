@@ -146,10 +146,11 @@ T* bp(auv_sim* h, int which) {
 // NULL is HIP's default (null) stream, exactly as in the HIP API itself
 hipStream_t pick(auv_sim*, void* stream) { return (hipStream_t)stream; }
 
-// Pair-list slots for a tile of `te` envs: room for ~4 candidate rays per
-// primitive without a second round, between 1024 and 4096, a power of two.
+// Pair-list slots for a tile of `te` envs: room for ~12 candidate rays per
+// circle and ~3 per polygon edge (circles are the wide primitives) without a
+// second round, between 256 and 4096, a power of two.
 int pair_cap(const Dims& d, int te) {
-    const long long want = (long long)te * (d.C + d.P * d.NV) * 4;
+    const long long want = (long long)te * (12LL * d.C + 3LL * d.P * d.NV);
     int cap = 256;
     while (cap < 4096 && cap < want) cap <<= 1;
     return cap;

@@ -1,6 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd $R
-for args in "--workload cfg5_dense_720 --steps 100" "--workload cfg5_dense_720 --steps 100 --no-auto-reset" "" "--workload cfg2_4096_static"; do
+for args in "--workload cfg2_4096_static" "--workload cfg2_4096_static --tile 2" "--workload cfg2_4096_static --tile 8" "" "--workload cfg5_dense_720 --steps 100" "--workload cfg1_single_episode --steps 1000"; do
   timeout -k 10 120 python bench.py --no-cpu-baseline --cnn none $args > gpurun_out/ab.log 2>&1 || { tail -5 gpurun_out/ab.log; continue; }
   python -c "
 import json
