@@ -49,7 +49,7 @@ EXPORTS = (
     "auv_get_buffer", "auv_read_buffer", "auv_dlpack", "auv_sync", "auv_set_option",
     "auv_profile_enable", "auv_cnn_n_weights", "auv_cnn_out_dim", "auv_cnn_create", "auv_cnn_destroy",
     "auv_cnn_forward", "auv_cnn_last_error", "auv_format_rows",
-    "auv_profile_read", "auv_attach_cnn", "auv_generate_scene",
+    "auv_profile_read", "auv_attach_cnn", "auv_generate_scene", "auv_host_alloc", "auv_host_free",
 )
 
 
@@ -149,6 +149,10 @@ def load():
     lib.auv_cnn_last_error.argtypes = [vp]
     lib.auv_generate_scene.restype = C.c_int
     lib.auv_generate_scene.argtypes = [vp, C.c_uint64, C.POINTER(AuvSceneParams), vp]
+    lib.auv_host_alloc.restype = vp
+    lib.auv_host_alloc.argtypes = [i64]
+    lib.auv_host_free.restype = None
+    lib.auv_host_free.argtypes = [vp]
     lib.auv_attach_cnn.restype = C.c_int
     lib.auv_attach_cnn.argtypes = [vp, vp, i32]
     _lib = lib

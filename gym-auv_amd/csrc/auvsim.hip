@@ -793,6 +793,16 @@ int auv_read_buffer(auv_handle h, int which, void* host_dst, int64_t nbytes, voi
     return AUV_OK;
 }
 
+void* auv_host_alloc(int64_t nbytes) {
+    void* p = nullptr;
+    if (nbytes <= 0 || hipHostMalloc(&p, (size_t)nbytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void auv_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int auv_sync(auv_handle h, void* stream) {
     if (!h) return AUV_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->device));

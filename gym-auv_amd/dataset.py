@@ -105,10 +105,10 @@ class DatasetLogger:
         if self._k % self.every:
             return 0
         sim = self.sim
-        dist = sim.read("obst_dist", stream)
+        dist = sim.read("obst_dist", stream, pinned=True)
         tracked = np.isfinite(dist) & (dist < sim.cfg["sensor_range"])
-        return self.writer.write(sim.read("ranges", stream), sim.read("own", stream), sim.read("meta", stream),
-                                 sim.read("risk", stream), tracked)
+        return self.writer.write(sim.read("ranges", stream, pinned=True), sim.read("own", stream, pinned=True),
+                                 sim.read("meta", stream, pinned=True), sim.read("risk", stream, pinned=True), tracked)
 
 
 def save_binary(path, ranges, own, meta, risk, tracked):

@@ -50,6 +50,7 @@ class AuvSim:
     def __init__(self, cfg: dict, device: int = 0, ray_dirs=None):
         self._lib = _lib.load()
         self._h = C.c_void_p()
+        self._staging = {}
         self.cfg = dict(cfg)
         self.device = int(device)
         c = _lib.AuvConfig()
@@ -78,6 +79,9 @@ class AuvSim:
     # -- lifetime ---------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            for p, _ in self._staging.values():
+                self._lib.auv_host_free(p)
+            self._staging = {}
             self._lib.auv_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -166,11 +170,27 @@ class AuvSim:
         self._check(self._lib.auv_get_buffer(self._h, which, C.byref(p), shape, C.byref(nd), C.byref(dt)))
         return p.value, tuple(shape[i] for i in range(nd.value)), dt.value
 
-    def read(self, name, stream=None):
-        """Host copy of a buffer as a numpy array (synchronises)."""
+    def _pinned(self, which, shape, dtype):
+        """Page-locked staging array for buffer `which` (kept until close)."""
+        key = (which, tuple(shape))
+        hit = self._staging.get(key)
+        if hit is None:
+            nbytes = max(1, int(np.prod(shape)) * np.dtype(dtype).itemsize)
+            p = self._lib.auv_host_alloc(nbytes)
+            if not p:
+                raise MemoryError(f"cannot page-lock {nbytes} bytes")
+            arr = np.frombuffer((C.c_char * nbytes).from_address(p), dtype=dtype, count=int(np.prod(shape)))
+            hit = self._staging[key] = (p, arr.reshape(shape))
+        return hit[1]
+
+    def read(self, name, stream=None, pinned=False):
+        """Host copy of a buffer as a numpy array (synchronises).  pinned=True:
+        the copy lands in a page-locked staging array that belongs to this
+        object and is overwritten by the next pinned read of the same buffer
+        (about 3x the copy rate of pageable memory; for per-step readers)."""
         which = _lib.BUFFER_NAMES[name] if isinstance(name, str) else int(name)
         _, shape, dt = self.buffer(which)
-        out = np.empty(shape, dtype=_NP_DTYPE[dt])
+        out = self._pinned(which, shape, _NP_DTYPE[dt]) if pinned else np.empty(shape, dtype=_NP_DTYPE[dt])
         self._check(self._lib.auv_read_buffer(self._h, which, _ptr(out), out.nbytes, _stream_handle(stream)))
         return out
 

@@ -199,6 +199,13 @@ int auv_get_buffer(auv_handle h, int which, void** dev_ptr, int64_t* shape,
 /* Copy a buffer to host memory (synchronises `stream`). */
 int auv_read_buffer(auv_handle h, int which, void* host_dst, int64_t nbytes, void* stream);
 
+/* Page-locked host memory for auv_read_buffer / auv_step_host / auv_reset: copies
+ * to and from it run at the full PCIe rate (pageable memory is staged by the
+ * runtime at roughly a third of it).  NULL when the allocation fails.  No
+ * counterpart in the reference (its env lives in host memory). */
+void* auv_host_alloc(int64_t nbytes);
+void auv_host_free(void* p);
+
 /* Borrow a device buffer as a DLPack DLManagedTensor* (device type kDLROCM),
  * malloc'ed by the library; the consumer's call of its deleter frees the
  * record, never the buffer.  A Python caller wraps the pointer in a PyCapsule

@@ -120,3 +120,42 @@ def test_attached_cnn_rejects_other_scan_widths(gold):
         sim.attach_cnn(net, "features")
     net.close()
     sim.close()
+
+
+def test_dataset_logger_writes_the_oracles_rows(tmp_path):
+    """config 5's use: regenerate the three dataset files from a running batch.
+    The logger (page-locked reads every 5th step, native formatter) must write
+    byte for byte what the same writer produces from the oracle's buffers, and
+    the loader must read it back (utils/dataloader.py:55-56,104-120 semantics)."""
+    from gym_auv_amd import dataset as D
+    from gym_auv_amd import params
+    from tests.helpers import make_oracle
+
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=150)
+    sim = make_sim(cfg, scene)
+    env = make_oracle(cfg, scene)
+    sim.reset(scene["init_state"])
+    env.reset(scene["init_state"])
+    acts = scenarios.random_actions(150, 15, seed=4)
+    dev_dir, ora_dir = str(tmp_path / "dev"), str(tmp_path / "ora")
+    wd, wo = D.DatasetWriter(dev_dir), D.DatasetWriter(ora_dir)
+    logger = D.DatasetLogger(sim, wd, every=5)
+    rows = 0
+    for k in range(15):
+        sim.step_host(acts[k])
+        env.step(acts[k])
+        rows += logger.after_step()
+        if (k + 1) % 5 == 0:
+            tracked = np.isfinite(env.obst_dist) & (env.obst_dist < cfg["sensor_range"])
+            wo.write(env.ranges, env.own, env.meta, env.risk, tracked)
+    wd.close()
+    wo.close()
+    assert rows == wo.rows > 0
+    for kind in ("LiDAR", "risk", "metadata"):
+        assert open(wd.paths[kind], "rb").read() == open(wo.paths[kind], "rb").read(), kind
+    data = D.load_lidar_dataset(wd.paths["LiDAR"], wd.paths["risk"], mode="max")
+    n_train, n_val, n_test = D.split_sizes(rows)
+    assert data["train"][0].shape == (n_train, 1, 180) and data["test"][1].shape == (n_test, 1)
+    # a page-locked read returns the same bytes as a plain one
+    assert np.array_equal(sim.read("ranges", pinned=True), sim.read("ranges"))
+    sim.close()
