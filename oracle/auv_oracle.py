@@ -517,15 +517,18 @@ class OracleEnv:
     def set_path(self, path):
         self.path = np.array(path, dtype=np.float64, copy=True)
 
-    def generate_scene(self, seed, params=None):
-        """Scene, paths and initial states of every env from the generator, episode 0."""
+    def generate_scene(self, seed, params=None, env_ids=None):
+        """Scene, paths and initial states of every env from the generator, episode 0.
+        env_ids: the generator's env numbers of this oracle's envs (default 0..V-1;
+        a sample of a larger batch passes the sampled indices)."""
         from oracle import scene_oracle
 
         V = self.state.shape[1]
         C, P, NV = self.cfg["n_circles"], self.cfg["n_polys"], self.cfg["n_verts"]
         self.generator = (int(seed), params)
+        self.env_ids = np.arange(V) if env_ids is None else np.asarray(env_ids, dtype=np.int64)
         self.episode[:] = 0
-        sc = scene_oracle.generate(int(seed), np.arange(V), self.episode, C, P, NV, params)
+        sc = scene_oracle.generate(int(seed), self.env_ids, self.episode, C, P, NV, params)
         self.set_scene(sc["circles"], sc["poly_pose"], sc["poly_verts"], sc["poly_nv"], sc["poly_heading"])
         self.set_path(sc["path"])
         self.init0 = sc["init_state"]
@@ -591,7 +594,7 @@ class OracleEnv:
                 from oracle import scene_oracle
 
                 C, P, NV = cfg["n_circles"], cfg["n_polys"], cfg["n_verts"]
-                sc = scene_oracle.generate(self.generator[0], np.nonzero(restart)[0], self.episode[restart], C, P, NV,
+                sc = scene_oracle.generate(self.generator[0], self.env_ids[restart], self.episode[restart], C, P, NV,
                                            self.generator[1])
                 self.circles0[restart] = sc["circles"]
                 self.poly_pose0[restart] = sc["poly_pose"]
