@@ -41,7 +41,13 @@ def load():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise ImportError(f"{LIB_PATH} is missing: run `make -C oracle`")
+            # the checker builds itself where a C compiler is at hand (seconds)
+            import subprocess
+
+            try:
+                subprocess.run(["make", "-C", os.path.dirname(os.path.abspath(__file__)), "-s"], check=True)
+            except (OSError, subprocess.CalledProcessError) as e:
+                raise ImportError(f"{LIB_PATH} is missing and `make -C oracle` failed: {e}")
         _lib = C.CDLL(LIB_PATH)
         _lib.oc_run.restype = None
         _lib.oc_run.argtypes = [C.POINTER(OcConfig), C.POINTER(OcBuffers), C.c_void_p, C.c_int32, C.c_int32]
