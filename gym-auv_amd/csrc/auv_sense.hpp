@@ -561,6 +561,7 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
             const int used = atomicAdd(&wsum[15], iv.y);
             const int top = cap - used;  // exclusive upper slot of this primitive's run
             const int room = min(iv.y, top);
+#pragma nounroll  // a handful of rays per edge: the unrolled form only adds set-up
             for (int kk = 0; kk < room; ++kk)
                 pairs[top - 1 - kk] = ((unsigned int)(n_circ + i) << 16) | (unsigned int)kk;
         }
