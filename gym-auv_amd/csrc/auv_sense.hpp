@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
     if (threadIdx.x == 0) rs_n = 0;
     __syncthreads();
     bool restart = live && a.do_step && a.auto_reset && a.done[i] != 0;
-    if (restart) rs_env[atomicAdd(&rs_n, 1)] = i;
+    if (restart) rs_env[atomicAdd(&rs_n, 1)] = i;  // at most one entry per thread of the 256
     __syncthreads();
     const int n_el = a.C * 5, n_rec = a.C * 5 + a.P * 6;  // doubles per env: circles, then polygon poses
     const int n_items = rs_n * n_rec;
@@ -342,6 +342,19 @@ __device__ long long* g_stamps = nullptr;
 #define AUV_STAMP(n)
 #endif
 
+// Debug builds (-DAUV_DEBUG_BOUNDS) count every violated index bound of the
+// on-chip arrays instead of trusting the layout arithmetic; the product build
+// compiles the checks away.
+#ifdef AUV_DEBUG_BOUNDS
+__device__ unsigned long long g_violations = 0ull;
+#define AUV_CHECK(cond)                                  \
+    do {                                                 \
+        if (!(cond)) atomicAdd(&g_violations, 1ull);     \
+    } while (0)
+#else
+#define AUV_CHECK(cond)
+#endif
+
 constexpr int kKeep = 4;  // pair-list passes whose hit keys stay in registers between the two sweeps
 
 __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
@@ -453,10 +466,12 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
             const float hw = fast_atan2f(fr, fast_sqrtf(fmm - fr * fr)) * inv_delta;
             iv = make_interval(xc - hw, xc + hw, R, margin);
         }
+        AUV_CHECK(i >= 0 && i < TE * C && el >= 0 && el < ne && j >= 0 && j < C && iv.x >= 0 && iv.x < R && iv.y <= R);
         meta[i] = pack_meta(iv.x, iv.y, el, j);
         if (iv.y > 0) {
             const int base = atomicAdd(&wsum[14], iv.y);
             const int room = min(iv.y, cap - base);  // writes stay inside the list even when it overflows
+            AUV_CHECK(base >= 0 && (room <= 0 || base + room <= cap));
             for (int k = 0; k < room; ++k) pairs[base + k] = ((unsigned int)i << 16) | (unsigned int)k;
         }
     }
@@ -556,11 +571,13 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
         sg[4] = nt;
         edist[i] = dd;
         ecross[i] = k == 0 ? (cross | (nv << 1)) : cross;  // edge 0 also carries the vertex count
+        AUV_CHECK(i >= 0 && i < TE * S && el >= 0 && el < ne && q >= 0 && q < P && iv.x >= 0 && iv.x < R && iv.y <= R);
         meta[n_circ + i] = pack_meta(iv.x, iv.y, el, C + q);
         if (iv.y > 0) {
             const int used = atomicAdd(&wsum[15], iv.y);
             const int top = cap - used;  // exclusive upper slot of this primitive's run
             const int room = min(iv.y, top);
+            AUV_CHECK(top <= cap && (room <= 0 || top - room >= 0));
 #pragma nounroll  // a handful of rays per edge: the unrolled form only adds set-up
             for (int kk = 0; kk < room; ++kk)
                 pairs[top - 1 - kk] = ((unsigned int)(n_circ + i) << 16) | (unsigned int)kk;
@@ -598,6 +615,7 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
             if (o < C) return ob[OB_DIST * ob_n];
             const int s0 = el * S + (o - C) * NV;
             const int nv = ecross[s0] >> 1;
+            AUV_CHECK(s0 >= 0 && s0 + NV <= TE * S && nv >= 0 && nv <= NV);
             double dmin2 = __builtin_inf();
             int par = 0;
             for (int k = 0; k < nv; ++k) {
@@ -698,8 +716,10 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
             kept[j].ok = false;
             const int w = tid + j * nthr;
             if (w < total) {
+                AUV_CHECK((w < n_cp ? w : cap - n_ep + (w - n_cp)) >= 0 && (w < n_cp ? w : cap - n_ep + (w - n_cp)) < cap);
                 kept[j] = pair_test(pairs[w < n_cp ? w : cap - n_ep + (w - n_cp)], R, n_circ, range, meta, env, circ,
                                     seg, a.ray_dirs);
+                AUV_CHECK(!kept[j].ok || (kept[j].slot >= 0 && kept[j].slot < ne * R && (int)kept[j].oid < O));
                 if (kept[j].ok) atomicMin(&best[kept[j].slot], kept[j].key);
             }
         }
@@ -752,12 +772,14 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
                 for (int p = tid; p < NP; p += nthr) {
                     const int o = offs[p];
                     const int lo = max(o, w0), hi = min(o + meta_count(meta[p]), w0 + cap);
+                    AUV_CHECK(lo >= hi || (lo - w0 >= 0 && hi - w0 <= cap));
                     for (int w = lo; w < hi; ++w) pairs[w - w0] = ((unsigned int)p << 16) | (unsigned int)(w - o);
                 }
                 __syncthreads();
                 for (int w = tid; w < n_pairs; w += nthr) {
                     const PairHit h = pair_test(pairs[w], R, n_circ, range, meta, env, circ, seg, a.ray_dirs);
                     if (h.ok) {
+                        AUV_CHECK(h.slot >= 0 && h.slot < ne * R && (int)h.oid < O);
                         if (pass == 0) atomicMin(&best[h.slot], h.key);
                         else if (best[h.slot] == h.key) atomicMin(&ids[h.slot], h.oid);
                     }

@@ -937,6 +937,18 @@ int auv_profile_read(auv_handle h, double ms[3], int64_t* n_steps) {
     return AUV_OK;
 }
 
+#ifdef AUV_DEBUG_BOUNDS
+// debug builds only: violated index bounds counted by the kernels since the library was loaded
+int auv_debug_violations(int64_t* out) {
+    unsigned long long v = 0;
+    if (!out || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_violations), sizeof v) != hipSuccess)
+        return AUV_ERR_DEVICE;
+    *out = (int64_t)v;
+    return AUV_OK;
+}
+#endif
+
 #ifdef AUV_PHASE_STAMPS
 // diagnostic builds only: device buffer [blocks*4*16] of i64 that k_sense stamps
 int auv_debug_set_stamps(void* p) {
