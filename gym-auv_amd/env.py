@@ -47,7 +47,7 @@ class VecAuvEnv:
     """
 
     def __init__(self, cfg: dict, scene: dict | None, device: int = 0, auto_reset=True, seed: int = 0,
-                 gen_params: dict | None = None):
+                 gen_params: dict | None = None, cnn=None, cnn_head: str = "features"):
         import torch
 
         from . import _lib
@@ -79,6 +79,13 @@ class VecAuvEnv:
         self.action_space = Box(np.array([0.0, -1.0]), np.array([1.0, 1.0]), (2,))
         self._obs = {"perception": self.sim.tensor("perception"),
                      "navigation": self.sim.tensor("navigation")}
+        # a `cnn.LidarCNN` given here is evaluated inside every sensing pass; its
+        # output rides along as obs["cnn"] (B, out_dim): with the features head,
+        # what PerceptionNavigationExtractor computes from obs["perception"]
+        # (radarCNN.py:270-280) is then torch.cat([obs["cnn"], obs["navigation"][:, 0]], 1)
+        if cnn is not None:
+            self.sim.attach_cnn(cnn, cnn_head)
+            self._obs["cnn"] = self.sim.tensor("cnn_out")
         self._reward = self.sim.tensor("reward")
         self._done = self.sim.tensor("done")
         self._action = self.sim.tensor("action")   # f64 [2,V] staging

@@ -159,3 +159,23 @@ def test_dataset_logger_writes_the_oracles_rows(tmp_path):
     # a page-locked read returns the same bytes as a plain one
     assert np.array_equal(sim.read("ranges", pinned=True), sim.read("ranges"))
     sim.close()
+
+
+def test_vec_env_carries_the_attached_features(gold):
+    import torch
+
+    from gym_auv_amd.env import VecAuvEnv
+
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=257)
+    W = N.golden_weights(gold, "shallow")
+    net = cnn.LidarCNN("shallow", W)
+    env = VecAuvEnv(cfg, scene, auto_reset="device", cnn=net)
+    obs = env.reset()
+    ext = cnn.PerceptionNavigationExtractor("shallow", W)
+    for k in range(3):
+        want = ext({"perception": obs["perception"], "navigation": obs["navigation"]})
+        got = torch.cat([obs["cnn"], obs["navigation"][:, 0, :]], dim=1)
+        assert torch.equal(got, want)
+        a = torch.rand(257, 2, device="cuda")
+        obs, rew, done, info = env.step(a)
+    env.close()
