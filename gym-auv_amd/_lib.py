@@ -36,7 +36,9 @@ BUFFER_NAMES = {
 
 # auv_option
 OPT_LIDAR_MODE, OPT_RASTER_TILE, OPT_SENSE_BLOCK, OPT_AUTO_RESET, OPT_REGENERATE, OPT_META_EVERY = 0, 1, 2, 3, 4, 5
+OPT_RISK_MODEL = 6
 LIDAR_RASTER, LIDAR_ALL_PAIRS = 0, 1
+RISK_DEFAULT, RISK_REFERENCE = 0, 1
 
 # CNN consumers
 CNN_SHALLOW, CNN_2DEEP, CNN_DEEP = 0, 1, 2
@@ -50,6 +52,7 @@ EXPORTS = (
     "auv_profile_enable", "auv_cnn_n_weights", "auv_cnn_out_dim", "auv_cnn_create", "auv_cnn_destroy",
     "auv_cnn_forward", "auv_cnn_last_error", "auv_format_rows",
     "auv_profile_read", "auv_attach_cnn", "auv_generate_scene", "auv_host_alloc", "auv_host_free",
+    "auv_risk_rows",
 )
 
 
@@ -155,5 +158,7 @@ def load():
     lib.auv_host_free.argtypes = [vp]
     lib.auv_attach_cnn.restype = C.c_int
     lib.auv_attach_cnn.argtypes = [vp, vp, i32]
+    lib.auv_risk_rows.restype = C.c_int
+    lib.auv_risk_rows.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib

@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "auv_math.hpp"
+#include "auv_risk.hpp"
 
 namespace auv {
 
@@ -242,6 +243,7 @@ struct EncArgs {
     double rw_progress, rw_collision, rw_goal, rw_cte;
     int max_steps;
     int is_step;  // 1: called from a step (reward from progress), 0: after reset
+    int risk_model;  // 0: default index, 1: the reference's index (auv_risk.hpp)
 };
 
 __device__ __forceinline__ double poly_signed_distance(const double* pose, const double* verts, int nv,
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(256) void k_encounter(EncArgs a) {
         const double fc = 1.0 - (dcpa < R ? dcpa : R) / R;
         const double term_c = (a.w_c * (fc * fc)) * (a.t_c / (a.t_c + tcpa));
         const double rr = term_d + (has_c ? term_c : 0.0);
-        a.risk[eo] = inrange ? rr : 0.0;
+        a.risk[eo] = a.risk_model == 1 ? risk_reference(mx, my, vx, vy, rvx, rvy, dist, psi, R) : (inrange ? rr : 0.0);
     }
     __syncthreads();
     for (int el = threadIdx.x; el < ne; el += blockDim.x) {

@@ -22,6 +22,7 @@
 #pragma once
 #include "auv_cnn.hpp"
 #include "auv_lidar_raster.hpp"
+#include "auv_risk.hpp"
 
 namespace auv {
 
@@ -357,6 +358,8 @@ __device__ unsigned long long g_violations = 0ull;
 
 constexpr int kKeep = 4;  // pair-list passes whose hit keys stay in registers between the two sweeps
 
+// RISK: 0 = default risk index, 1 = the reference's index (auv_risk.hpp)
+template <int RISK>
 __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int V = a.d.V, R = a.d.R, C = a.d.C, P = a.d.P, NV = a.d.NV, O = a.d.O;
@@ -661,8 +664,15 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
                         m[1] = dist;
                         m[2] = __builtin_sqrt(rvx * rvx + rvy * rvy);
                     } else if (task == 3) {
-                        a.risk[eo] = risk_index(mx, my, rvx, rvy, rvx * rvx + rvy * rvy, hull_distance(ob, el, o), range,
-                                                a.inv_range, a.w_d, a.w_c, a.t_c);
+                        if (RISK == 1) {
+                            const double* ov = o < C ? a.circles + ((size_t)e * C + o) * 5 + 3
+                                                     : a.poly_pose + ((size_t)e * P + (o - C)) * 6 + 4;
+                            a.risk[eo] = risk_reference(mx, my, ov[0], ov[1], rvx, rvy, hull_distance(ob, el, o),
+                                                        a.state[2 * (size_t)V + e], range);
+                        } else {
+                            a.risk[eo] = risk_index(mx, my, rvx, rvy, rvx * rvx + rvy * rvy, hull_distance(ob, el, o), range,
+                                                    a.inv_range, a.w_d, a.w_c, a.t_c);
+                        }
                     } else {
                         const double psi = a.state[2 * (size_t)V + e];
                         m[2 + task] = wrap_angle(atan2_det(task == 1 ? my : rvy, task == 1 ? mx : rvx) - psi);

@@ -77,6 +77,7 @@ struct auv_sim {
     int auto_reset = 0;   // done envs restart inside the next step
     int regenerate = 0;   // ... with a newly generated scene
     int meta_every = 1;   // steps between refreshes of bearing / course / risk (0: only outside steps)
+    int risk_model = AUV_RISK_DEFAULT;
     long long step_count = 0;
     bool have_generator = false, have_init = false;
     uint64_t gen_seed = 0;
@@ -351,7 +352,10 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.cnn_kind = h->cnn_kind;
     sa.cnn_head = h->cnn_head;
     const int blocks = (d.V + h->raster_te - 1) / h->raster_te;
-    hipLaunchKernelGGL(k_sense, dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
+    if (h->risk_model == AUV_RISK_REFERENCE)
+        hipLaunchKernelGGL(k_sense<1>, dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
+    else
+        hipLaunchKernelGGL(k_sense<0>, dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
     HIP_TRY(h, hipGetLastError());
     if (h->cnn_w && !cnn_inside) {
         int rc = launch_cnn(h, st);  // the large network keeps a launch of its own
@@ -403,6 +407,7 @@ int launch_sense(auv_sim* h, hipStream_t st, hipEvent_t* ev, int is_step) {
     ea.rw_goal = h->cfg.reward[2];
     ea.rw_cte = h->cfg.reward[3];
     ea.is_step = is_step;
+    ea.risk_model = h->risk_model;
     const int enc_blocks = (d.V + h->enc_eb - 1) / h->enc_eb;
     hipLaunchKernelGGL(k_encounter, dim3(enc_blocks), dim3(256), h->enc_lds, st, ea);
     HIP_TRY(h, hipGetLastError());
@@ -544,7 +549,9 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     d.O = d.C + d.P;
     choose_geometry(h);
     // dynamic LDS beyond the 64 KiB default window has to be granted per kernel
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sense), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sense<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kLdsMax) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_sense<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsMax) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_lidar), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsMax) != hipSuccess) {
@@ -893,6 +900,11 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
             h->meta_every = value;
             h->step_count = 0;
             return AUV_OK;
+        case AUV_OPT_RISK_MODEL:
+            if (value != AUV_RISK_DEFAULT && value != AUV_RISK_REFERENCE)
+                return fail(h, AUV_ERR_ARG, "auv_set_option: AUV_OPT_RISK_MODEL takes AUV_RISK_DEFAULT or AUV_RISK_REFERENCE");
+            h->risk_model = value;
+            return AUV_OK;
         case AUV_OPT_REGENERATE:
             if (value != 0 && value != 1) return fail(h, AUV_ERR_ARG, "auv_set_option: AUV_OPT_REGENERATE takes 0 or 1");
             if (value && !h->have_generator)
@@ -1087,6 +1099,27 @@ int auv_cnn_forward(auv_cnn_handle c, const float* scans, int64_t n_scans, int32
         hipLaunchKernelGGL(k_cnn, dim3(blocks), dim3(256), cnn_lds_bytes(a.kind), (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cnn_fail(c, AUV_ERR_DEVICE, "k_cnn launch failed: %s", hipGetErrorString(e));
+    return AUV_OK;
+}
+
+int auv_risk_rows(auv_handle h, int64_t n, const double* own_heading, const double* dist, const double* rel_speed,
+                  const double* bearing, const double* course, double* out, void* stream) {
+    if (!h) return AUV_ERR_ARG;
+    if (n < 0 || n > ((int64_t)1 << 31) * 128) return fail(h, AUV_ERR_ARG, "auv_risk_rows: bad record count %lld", (long long)n);
+    if (n == 0) return AUV_OK;
+    if (!own_heading || !dist || !rel_speed || !bearing || !course || !out)
+        return fail(h, AUV_ERR_ARG, "auv_risk_rows: null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    RiskRowsArgs a;
+    a.n = n;
+    a.own_heading = own_heading;
+    a.dist = dist;
+    a.rel_speed = rel_speed;
+    a.bearing = bearing;
+    a.course = course;
+    a.out = out;
+    hipLaunchKernelGGL(k_risk_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(h, hipGetLastError());
     return AUV_OK;
 }
 

@@ -75,6 +75,8 @@ class AuvSim:
         self.O = self.C + self.P
         _live.add(self)
         self.set_rays(ray_table(self.R) if ray_dirs is None else ray_dirs)
+        if int(cfg.get("risk_model", _lib.RISK_DEFAULT)) != _lib.RISK_DEFAULT:
+            self.set_option(_lib.OPT_RISK_MODEL, int(cfg["risk_model"]))
 
     # -- lifetime ---------------------------------------------------------
     def close(self):
@@ -210,6 +212,30 @@ class AuvSim:
         result is the buffer "cnn_out" [V,out_dim].  None detaches."""
         from .cnn import HEADS
         self._check(self._lib.auv_attach_cnn(self._h, None if cnn is None else cnn._h, HEADS[head]))
+
+    def risk_rows(self, own_heading, dist, rel_speed, bearing, course, stream=None):
+        """The reference's risk index (`RISK_REFERENCE`) of dataset records:
+        float64 CUDA tensors of n elements each (heading_OS and the obstacle's
+        dist, speed, bearing, course of a metadata row,
+        utils/explore_dataset.py:8,40-53) -> float64 CUDA tensor [n], the value
+        data/risk_*.csv holds for a static obstacle."""
+        import torch
+        cols = []
+        for t in (own_heading, dist, rel_speed, bearing, course):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.dim() == 1):
+                raise TypeError("risk_rows takes 1-D float64 CUDA tensors")
+            if t.device.index != self.device:
+                raise ValueError(f"risk_rows: tensor on cuda:{t.device.index}, simulation on cuda:{self.device}")
+            cols.append(t.contiguous())
+        n = cols[0].numel()
+        if any(t.numel() != n for t in cols):
+            raise ValueError("risk_rows: columns differ in length")
+        out = torch.empty(n, dtype=torch.float64, device=cols[0].device)
+        if stream is None:
+            stream = torch.cuda.current_stream(cols[0].device)
+        self._check(self._lib.auv_risk_rows(self._h, n, *[C.c_void_p(t.data_ptr()) for t in cols],
+                                            C.c_void_p(out.data_ptr()), _stream_handle(stream)))
+        return out
 
     # -- profiling ----------------------------------------------------------
     def profile(self, on: bool):

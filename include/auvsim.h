@@ -117,16 +117,25 @@ typedef enum auv_option {
     AUV_OPT_REGENERATE = 4,   /* 1: with AUV_OPT_AUTO_RESET, a restarting env also gets a NEW scene, path and
                                * initial state from the generator (auv_generate_scene must have been called),
                                * for episode number AUV_BUF_EPISODE + 1; default 0: same scene every episode */
-    AUV_OPT_META_EVERY = 5    /* n: the per-obstacle bearing, course (AUV_BUF_META fields 3, 4) and AUV_BUF_RISK
+    AUV_OPT_META_EVERY = 5,   /* n: the per-obstacle bearing, course (AUV_BUF_META fields 3, 4) and AUV_BUF_RISK
                                * are refreshed only by every n-th auv_step since this call (and by every
                                * auv_reset / auv_sense); in between they keep their last values.  The
                                * reference logs them about every 5th step (dataset rows); a policy does not
                                * read them.  0: never during steps.  Default 1: every step.  Distances,
                                * collision, reward and the observations are always current.  Rasterising
                                * path only (the all-pairs path always refreshes). */
+    AUV_OPT_RISK_MODEL = 6    /* which index fills AUV_BUF_RISK.  AUV_RISK_DEFAULT: the closest-point-of-approach
+                               * index weighted by auv_config.risk.  AUV_RISK_REFERENCE: the reference's own
+                               * index as recovered from data/metadata_MovingObstaclesNoRules.csv against
+                               * data/risk_MovingObstaclesNoRules.csv (0.2 bearing + 0.3 DCPA x TCPA + 0.3 range
+                               * memberships, in the reference's frames); it reproduces the 14,102 records of
+                               * static obstacles in those files to 2e-15.  The records of moving obstacles are
+                               * not reproduced: for obstacles with a velocity it is an extrapolation. */
 } auv_option;
 #define AUV_LIDAR_RASTER 0
 #define AUV_LIDAR_ALL_PAIRS 1
+#define AUV_RISK_DEFAULT 0
+#define AUV_RISK_REFERENCE 1
 
 /* Library build information: "libauvsim <abi> gfx950 ...". */
 const char* auv_version(void);
@@ -235,6 +244,16 @@ int auv_profile_read(auv_handle h, double ms[3], int64_t* n_steps);
  * + 1 per row always suffice), AUV_ERR_ARG on a null pointer. */
 int64_t auv_format_rows(const double* values, const int32_t* row_len, int64_t n_rows, int64_t stride,
                         char* out, int64_t out_cap);
+
+/* ---- dataset records -> risk (device pointers) -----------------------------
+ * The AUV_RISK_REFERENCE index evaluated on n dataset records: per obstacle
+ * record of a metadata row (utils/explore_dataset.py:8,40-53) the vessel's
+ * heading_OS and the obstacle's dist, speed, bearing and course; out[i] is the
+ * value the reference logged in data/risk_*.csv for a static obstacle
+ * (utils/dataloader.py:108 reads those files).  All pointers are f64 device
+ * arrays of n elements on the handle's GPU.  Asynchronous on `stream`. */
+int auv_risk_rows(auv_handle h, int64_t n, const double* own_heading, const double* dist, const double* rel_speed,
+                  const double* bearing, const double* course, double* out, void* stream);
 
 /* ---- LiDAR-CNN consumers of the scan (fp32, 180-ray scans) -----------------
  * Forward passes of the three reference networks, reading the perception

@@ -53,6 +53,7 @@ enum { MP_MINV11, MP_MINV22, MP_MINV23, MP_MINV32, MP_MINV33, MP_M11, MP_M22, MP
 
 typedef struct {
     int32_t V, R, C, P, NV, max_steps;
+    int32_t risk_model, pad_;   /* 0: default index, 1: oc_risk_reference */
     double dt, sensor_range, vessel_radius, thrust_max, moment_max, look_ahead, goal_radius;
     double risk[3], reward[4], model[16];
 } oc_config;
@@ -71,6 +72,39 @@ typedef struct {
     double *min_dist; int32_t *min_idx; double *own, *meta, *risk; float *navigation;
     uint8_t *reached_goal, *truncated, *done; double *reward;
 } oc_buffers;
+
+/* oracle/ref_cri.py: bearing_membership, cri_core, risk_reference -- the
+ * reference's risk index for static obstacles as recovered from its dataset
+ * files (data/metadata_MovingObstaclesNoRules.csv, data/risk_MovingObstaclesNoRules.csv). */
+static double oc_cri_core(double px, double py, double vx, double vy, int moving, double d, double b) {
+    const double D1 = 32.0, D2 = 160.0, DA = 20.08, DB = 45.18;
+    const double along = px * vx + py * vy;
+    const double cross = px * vy - py * vx;
+    const double dc = fabs(cross), ln = fabs(along);
+    const int near = dc <= D1;
+    const double lin = (D2 - dc) / (D2 - D1);
+    const double u_dc = near ? 1.0 : (lin > 0.0 ? lin : 0.0);
+    const double r2 = D2 * D2 - dc * dc;
+    const double t2 = sqrt(r2 > 0.0 ? r2 : 0.0);
+    const double r1 = D1 * D1 - dc * dc;
+    const double t1 = near ? sqrt(r1 > 0.0 ? r1 : 0.0) : D1 - dc;
+    const double den = t2 - t1;
+    double q = (t2 - ln) / (den > 0.0 ? den : 1.0);
+    q = q > 0.0 ? q : 0.0;
+    q = q < 1.0 ? q : 1.0;
+    const double u_ta = ln <= t1 ? 1.0 : q;
+    const double o = 1.0 - ln / D1;
+    const double u_tr = o > 0.0 ? o : 0.0;
+    const double u_t = along < 0.0 ? u_ta : u_tr;
+    const double ct = moving ? (0.3 * u_dc) * u_t : 0.0;
+    double qd = (DB - d) / (DB - DA);
+    qd = qd > 0.0 ? qd : 0.0;
+    const double u_d = d <= DA ? 1.0 : qd * qd;
+    const double bd = b * 57.29577951308232;
+    const double q1 = (90.0 - bd) / 80.0, q2 = (bd + 270.0) / 225.0;
+    const double u_b = bd < -45.0 ? q2 * q2 : (bd <= 10.0 ? 1.0 : (bd < 90.0 ? q1 * q1 : 0.0));
+    return (0.2 * u_b + ct) + 0.3 * u_d;
+}
 
 /* oracle/auv_oracle.py: sincos */
 static void oc_sincos(double x, double *s, double *c) {
@@ -112,6 +146,24 @@ static double oc_atan2(double y, double x) {
 }
 
 static double oc_wrap(double a) { return a - floor((a + PI) * INV_TWO_PI) * TWO_PI; }
+
+/* oracle/ref_cri.py: risk_reference */
+static double oc_risk_reference(double mx, double my, double ovx, double ovy, double rvx, double rvy, double dist,
+                                double psi, double range) {
+    const double n = sqrt(mx * mx + my * my);
+    const int has_n = n > 0.0;
+    const double ns = has_n ? n : 1.0;
+    const double ux = has_n ? mx / ns : 1.0, uy = has_n ? my / ns : 0.0;
+    const double vv = rvx * rvx + rvy * rvy;
+    const int still = ovx == 0.0 && ovy == 0.0;
+    const double sp = sqrt(vv);
+    const double sps = vv > 0.0 ? sp : 1.0;
+    const double dvx = still ? (psi > 0.0 ? 1.0 : -1.0) : rvx / sps;
+    const double dvy = still ? 0.0 : rvy / sps;
+    const double b = oc_wrap(oc_atan2(my, mx) - psi);
+    const double r = oc_cri_core(dist * ux, dist * uy, dvx, dvy, vv > 0.0, dist, b);
+    return dist < range ? r : 0.0;
+}
 
 /* oracle/auv_oracle.py: vessel_rhs */
 static void oc_rhs(const double y[6], double fx, double mz, const double *mp, double out[6]) {
@@ -311,7 +363,8 @@ static void oc_sense_env(const oc_config *cf, const oc_buffers *b, int e, int is
         const double fc = 1.0 - fmin(dcpa, range) / range;
         const double term_c = (w_c * (fc * fc)) * (t_c / (t_c + tcpa));
         const double rr = term_d + (has_c ? term_c : 0.0);
-        b->risk[(size_t)e * O + o] = inrange ? rr : 0.0;
+        b->risk[(size_t)e * O + o] = cf->risk_model == 1
+            ? oc_risk_reference(mx, my, vx, vy, rvx, rvy, dist[o], psi, range) : (inrange ? rr : 0.0);
     }
 
     /* navigation, flags, reward */

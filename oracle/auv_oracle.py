@@ -562,8 +562,12 @@ class OracleEnv:
                                             cfg["vessel_radius"])
         self.own, self.meta = encounter_metadata(self.state, self.circles, self.poly_pose,
                                                  self.poly_heading, self.obst_dist)
-        self.risk = risk_default(self.state, self.circles, self.poly_pose, self.obst_dist,
-                                 R, cfg["risk"])
+        if int(cfg.get("risk_model", 0)) == 1:
+            from .ref_cri import risk_reference
+            self.risk = risk_reference(self.state, self.circles, self.poly_pose, self.obst_dist, R)
+        else:
+            self.risk = risk_default(self.state, self.circles, self.poly_pose, self.obst_dist,
+                                     R, cfg["risk"])
         self.perception = closeness(self.ranges, R)
         prev_along = getattr(self, "along", None)
         nav, self.along = navigation_features(self.state, self.path, cfg["look_ahead"])

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "l
 
 class OcConfig(C.Structure):
     _fields_ = [("V", C.c_int32), ("R", C.c_int32), ("C", C.c_int32), ("P", C.c_int32), ("NV", C.c_int32),
-                ("max_steps", C.c_int32),
+                ("max_steps", C.c_int32), ("risk_model", C.c_int32), ("pad_", C.c_int32),
                 ("dt", C.c_double), ("sensor_range", C.c_double), ("vessel_radius", C.c_double),
                 ("thrust_max", C.c_double), ("moment_max", C.c_double), ("look_ahead", C.c_double),
                 ("goal_radius", C.c_double), ("risk", C.c_double * 3), ("reward", C.c_double * 4),
@@ -63,6 +63,7 @@ class COracleEnv:
         O = Cn + P
         c = OcConfig()
         c.V, c.R, c.C, c.P, c.NV, c.max_steps = V, R, Cn, P, NV, cfg["max_steps"]
+        c.risk_model = int(cfg.get("risk_model", 0))
         for k in ("dt", "sensor_range", "vessel_radius", "thrust_max", "moment_max", "look_ahead", "goal_radius"):
             setattr(c, k, float(cfg[k]))
         c.risk[:] = [float(x) for x in cfg["risk"]]
