@@ -159,6 +159,6 @@ def load():
     lib.auv_attach_cnn.restype = C.c_int
     lib.auv_attach_cnn.argtypes = [vp, vp, i32]
     lib.auv_risk_rows.restype = C.c_int
-    lib.auv_risk_rows.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp]
+    lib.auv_risk_rows.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib

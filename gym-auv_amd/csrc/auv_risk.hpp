@@ -1,17 +1,17 @@
-// The reference's collision-risk index for static obstacles, as recovered
-// from its dataset files (data/metadata_MovingObstaclesNoRules.csv against
+// The reference's collision-risk index, as recovered from its dataset files
+// (data/metadata_MovingObstaclesNoRules.csv against
 // data/risk_MovingObstaclesNoRules.csv; record layout
-// utils/explore_dataset.py:8,40-53): it reproduces all 14,102 static-obstacle
-// records to 2e-15.  The records of moving obstacles are not reproduced; for
-// them the index is an extrapolation.
+// utils/explore_dataset.py:8,40-53): it reproduces all 23,680 per-obstacle
+// records of those files (14,102 static, 9,578 moving) to 2e-15.
 //
-//   risk = 0.2 u_B(bearing) + 0.3 u_DCPA u_TCPA + 0.3 u_D(dist)
+//   risk = max(0, 0.2 u_B(bearing) + 0.3 u_DCPA u_TCPA + 0.3 u_D(dist) + 0.2 u_A)
 //
 // p is the obstacle position (hull distance along the world-frame direction
-// of the obstacle), v the unit direction of the relative course; the
-// reference takes 0 / -pi for that course of a static obstacle by the sign of
-// the vessel's heading.  Unfused fp64 in this operation order: bit-equal to
-// the numpy and C restatements of the same index.
+// of the obstacle), v the unit direction of the relative course as the
+// reference forms it, u_A = cos(a)|cos(a)| of the vessel's bearing a seen from
+// a moving obstacle relative to that obstacle's heading (0 for a static one).
+// Unfused fp64 in this operation order: bit-equal to the numpy and C
+// restatements of the same index.
 #pragma once
 #include "auv_math.hpp"
 
@@ -20,7 +20,7 @@ namespace auv {
 constexpr double kCriRad2Deg = 57.29577951308232;
 constexpr double kCriD1 = 32.0, kCriD2 = 160.0;      // CPA distances: full risk / none
 constexpr double kCriDa = 20.08, kCriDb = 45.18;     // range term: full risk / none
-constexpr double kCriWb = 0.2, kCriWct = 0.3, kCriWd = 0.3;
+constexpr double kCriWb = 0.2, kCriWct = 0.3, kCriWd = 0.3, kCriWa = 0.2;
 
 __device__ __forceinline__ double cri_bearing_membership(double b) {
     const double bd = b * kCriRad2Deg;
@@ -29,7 +29,8 @@ __device__ __forceinline__ double cri_bearing_membership(double b) {
     return bd < -45.0 ? q2 * q2 : (bd <= 10.0 ? 1.0 : (bd < 90.0 ? q1 * q1 : 0.0));
 }
 
-__device__ __forceinline__ double cri_core(double px, double py, double vx, double vy, bool moving, double d, double b) {
+__device__ __forceinline__ double cri_core(double px, double py, double vx, double vy, bool moving, double d, double b,
+                                           double aspect) {
     const double along = px * vx + py * vy;
     const double cross = px * vy - py * vx;
     const double dc = __builtin_fabs(cross);
@@ -53,34 +54,60 @@ __device__ __forceinline__ double cri_core(double px, double py, double vx, doub
     double qd = (kCriDb - d) / (kCriDb - kCriDa);
     qd = qd > 0.0 ? qd : 0.0;
     const double u_d = d <= kCriDa ? 1.0 : qd * qd;
-    return (kCriWb * cri_bearing_membership(b) + ct) + kCriWd * u_d;
+    const double total = ((kCriWb * cri_bearing_membership(b) + ct) + kCriWd * u_d) + kCriWa * aspect;
+    return total > 0.0 ? total : 0.0;
 }
 
-// One obstacle of a simulator state: m = centre relative to the vessel, (ovx,
-// ovy) the obstacle's own velocity, rv its velocity relative to the vessel,
-// dist the signed hull distance, psi the vessel's heading.
-__device__ __forceinline__ double risk_reference(double mx, double my, double ovx, double ovy, double rvx, double rvy,
+// One obstacle of a simulator state, its inputs formed the way the reference
+// forms them: m = centre relative to the vessel, (ovx, ovy) the obstacle's
+// velocity, (vox, voy) the vessel's, dist the signed hull distance, psi the
+// vessel's heading.  The vessel's velocity is taken as its speed along its
+// heading.  An obstacle without a velocity has the static course (+x for a
+// positive heading, -x otherwise) and no aspect term; one with a velocity is
+// headed along it, and the relative course is its velocity minus the
+// vessel's, the latter mirrored about the obstacle's heading when
+// heading_ts - heading_OS leaves (-pi, pi].
+__device__ __forceinline__ double risk_reference(double mx, double my, double ovx, double ovy, double vox, double voy,
                                                  double dist, double psi, double range) {
+    const SinCos sc = sincos_det(psi);
+    const double ss = __builtin_sqrt(vox * vox + voy * voy);
+    const double sx = ss * sc.c;
+    const double sy = ss * sc.s;
     const double n = __builtin_sqrt(mx * mx + my * my);
     const bool has_n = n > 0.0;
     const double ns = has_n ? n : 1.0;
     const double ux = has_n ? mx / ns : 1.0;
     const double uy = has_n ? my / ns : 0.0;
-    const double vv = rvx * rvx + rvy * rvy;
     const bool still = ovx == 0.0 && ovy == 0.0;
-    const double sp = __builtin_sqrt(vv);
-    const double sps = vv > 0.0 ? sp : 1.0;
-    const double dvx = still ? (psi > 0.0 ? 1.0 : -1.0) : rvx / sps;
-    const double dvy = still ? 0.0 : rvy / sps;
+    const double so = __builtin_sqrt(ovx * ovx + ovy * ovy);
+    const double sos = still ? 1.0 : so;
+    const double hx = ovx / sos;
+    const double hy = ovy / sos;
+    const double dl = atan2_det(ovy, ovx) - psi;
+    const bool mirror = __builtin_fabs(dl) > kPi;
+    const double dot = sx * hx + sy * hy;
+    const double ex = mirror ? (2.0 * dot) * hx - sx : sx;
+    const double ey = mirror ? (2.0 * dot) * hy - sy : sy;
+    const double rx = ovx - ex;
+    const double ry = ovy - ey;
+    const double rn = __builtin_sqrt(rx * rx + ry * ry);
+    const double rns = rn > 0.0 ? rn : 1.0;
+    const double dvx = still ? (psi > 0.0 ? 1.0 : -1.0) : rx / rns;
+    const double dvy = still ? 0.0 : ry / rns;
+    const bool moving = still ? ss > 0.0 : rn > 0.0;
+    const double ca = 0.0 - (ux * hx + uy * hy);
+    const double aspect = still ? 0.0 : ca * __builtin_fabs(ca);
     const double b = wrap_angle(atan2_det(my, mx) - psi);
-    const double r = cri_core(dist * ux, dist * uy, dvx, dvy, vv > 0.0, dist, b);
+    const double r = cri_core(dist * ux, dist * uy, dvx, dvy, moving, dist, b, aspect);
     return dist < range ? r : 0.0;
 }
 
-// Dataset records -> risk: one thread per record.
+// Dataset records -> risk: one thread per obstacle record of a metadata row.
 struct RiskRowsArgs {
     long long n;
+    const double* own_speed;
     const double* own_heading;
+    const double* heading_ts;
     const double* dist;
     const double* rel_speed;
     const double* bearing;
@@ -91,10 +118,14 @@ struct RiskRowsArgs {
 __global__ __launch_bounds__(256) void k_risk_rows(RiskRowsArgs a) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n) return;
-    const double d = a.dist[i], b = a.bearing[i];
-    const SinCos w = sincos_det(b + a.own_heading[i]);
+    const double d = a.dist[i], b = a.bearing[i], ht = a.heading_ts[i], rs = a.rel_speed[i];
+    const double bw = b + a.own_heading[i];
+    const SinCos w = sincos_det(bw);
     const SinCos c = sincos_det(a.course[i]);
-    a.out[i] = cri_core(d * w.c, d * w.s, c.c, c.s, a.rel_speed[i] > 0.0, d, b);
+    const bool is_static = ht == 0.0 && rs == a.own_speed[i];  // utils/explore_dataset.py:46
+    const double ca = sincos_det(bw - ht).c;                   // cos(a) = -cos(a - pi)
+    const double aspect = is_static ? 0.0 : 0.0 - ca * __builtin_fabs(ca);
+    a.out[i] = cri_core(d * w.c, d * w.s, c.c, c.s, rs > 0.0, d, b, aspect);
 }
 
 }  // namespace auv

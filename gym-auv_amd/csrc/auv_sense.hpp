@@ -667,8 +667,9 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
                         if (RISK == 1) {
                             const double* ov = o < C ? a.circles + ((size_t)e * C + o) * 5 + 3
                                                      : a.poly_pose + ((size_t)e * P + (o - C)) * 6 + 4;
-                            a.risk[eo] = risk_reference(mx, my, ov[0], ov[1], rvx, rvy, hull_distance(ob, el, o),
-                                                        a.state[2 * (size_t)V + e], range);
+                            const double* er = a.envrec + (size_t)e * ER_COUNT;
+                            a.risk[eo] = risk_reference(mx, my, ov[0], ov[1], er[ER_VOX], er[ER_VOY],
+                                                        hull_distance(ob, el, o), a.state[2 * (size_t)V + e], range);
                         } else {
                             a.risk[eo] = risk_index(mx, my, rvx, rvy, rvx * rvx + rvy * rvy, hull_distance(ob, el, o), range,
                                                     a.inv_range, a.w_d, a.w_c, a.t_c);

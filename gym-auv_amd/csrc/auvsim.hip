@@ -1102,17 +1102,20 @@ int auv_cnn_forward(auv_cnn_handle c, const float* scans, int64_t n_scans, int32
     return AUV_OK;
 }
 
-int auv_risk_rows(auv_handle h, int64_t n, const double* own_heading, const double* dist, const double* rel_speed,
-                  const double* bearing, const double* course, double* out, void* stream) {
+int auv_risk_rows(auv_handle h, int64_t n, const double* own_speed, const double* own_heading,
+                  const double* heading_ts, const double* dist, const double* rel_speed, const double* bearing,
+                  const double* course, double* out, void* stream) {
     if (!h) return AUV_ERR_ARG;
     if (n < 0 || n > ((int64_t)1 << 31) * 128) return fail(h, AUV_ERR_ARG, "auv_risk_rows: bad record count %lld", (long long)n);
     if (n == 0) return AUV_OK;
-    if (!own_heading || !dist || !rel_speed || !bearing || !course || !out)
+    if (!own_speed || !own_heading || !heading_ts || !dist || !rel_speed || !bearing || !course || !out)
         return fail(h, AUV_ERR_ARG, "auv_risk_rows: null argument");
     HIP_TRY(h, hipSetDevice(h->device));
     RiskRowsArgs a;
     a.n = n;
+    a.own_speed = own_speed;
     a.own_heading = own_heading;
+    a.heading_ts = heading_ts;
     a.dist = dist;
     a.rel_speed = rel_speed;
     a.bearing = bearing;

@@ -213,15 +213,15 @@ class AuvSim:
         from .cnn import HEADS
         self._check(self._lib.auv_attach_cnn(self._h, None if cnn is None else cnn._h, HEADS[head]))
 
-    def risk_rows(self, own_heading, dist, rel_speed, bearing, course, stream=None):
+    def risk_rows(self, own_speed, own_heading, heading_ts, dist, rel_speed, bearing, course, stream=None):
         """The reference's risk index (`RISK_REFERENCE`) of dataset records:
-        float64 CUDA tensors of n elements each (heading_OS and the obstacle's
-        dist, speed, bearing, course of a metadata row,
+        float64 CUDA tensors of n elements each (speed_OS, heading_OS and the
+        obstacle's heading_ts, dist, speed, bearing, course of a metadata row,
         utils/explore_dataset.py:8,40-53) -> float64 CUDA tensor [n], the value
-        data/risk_*.csv holds for a static obstacle."""
+        data/risk_*.csv holds for that record."""
         import torch
         cols = []
-        for t in (own_heading, dist, rel_speed, bearing, course):
+        for t in (own_speed, own_heading, heading_ts, dist, rel_speed, bearing, course):
             if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.dim() == 1):
                 raise TypeError("risk_rows takes 1-D float64 CUDA tensors")
             if t.device.index != self.device:

@@ -128,9 +128,8 @@ typedef enum auv_option {
                                * index weighted by auv_config.risk.  AUV_RISK_REFERENCE: the reference's own
                                * index as recovered from data/metadata_MovingObstaclesNoRules.csv against
                                * data/risk_MovingObstaclesNoRules.csv (0.2 bearing + 0.3 DCPA x TCPA + 0.3 range
-                               * memberships, in the reference's frames); it reproduces the 14,102 records of
-                               * static obstacles in those files to 2e-15.  The records of moving obstacles are
-                               * not reproduced: for obstacles with a velocity it is an extrapolation. */
+                               * + 0.2 target-aspect memberships, clipped at 0, in the reference's frames); it
+                               * reproduces all 23,680 per-obstacle records of those files to 2e-15. */
 } auv_option;
 #define AUV_LIDAR_RASTER 0
 #define AUV_LIDAR_ALL_PAIRS 1
@@ -248,12 +247,14 @@ int64_t auv_format_rows(const double* values, const int32_t* row_len, int64_t n_
 /* ---- dataset records -> risk (device pointers) -----------------------------
  * The AUV_RISK_REFERENCE index evaluated on n dataset records: per obstacle
  * record of a metadata row (utils/explore_dataset.py:8,40-53) the vessel's
- * heading_OS and the obstacle's dist, speed, bearing and course; out[i] is the
- * value the reference logged in data/risk_*.csv for a static obstacle
- * (utils/dataloader.py:108 reads those files).  All pointers are f64 device
- * arrays of n elements on the handle's GPU.  Asynchronous on `stream`. */
-int auv_risk_rows(auv_handle h, int64_t n, const double* own_heading, const double* dist, const double* rel_speed,
-                  const double* bearing, const double* course, double* out, void* stream);
+ * speed_OS and heading_OS and the obstacle's heading_ts, dist, speed, bearing
+ * and course; out[i] is the value the reference logged for that record in
+ * data/risk_*.csv (utils/dataloader.py:108 reads those files).  All pointers
+ * are f64 device arrays of n elements on the handle's GPU.  Asynchronous on
+ * `stream`. */
+int auv_risk_rows(auv_handle h, int64_t n, const double* own_speed, const double* own_heading,
+                  const double* heading_ts, const double* dist, const double* rel_speed, const double* bearing,
+                  const double* course, double* out, void* stream);
 
 /* ---- LiDAR-CNN consumers of the scan (fp32, 180-ray scans) -----------------
  * Forward passes of the three reference networks, reading the perception

@@ -74,9 +74,9 @@ typedef struct {
 } oc_buffers;
 
 /* oracle/ref_cri.py: bearing_membership, cri_core, risk_reference -- the
- * reference's risk index for static obstacles as recovered from its dataset
+ * reference's risk index as recovered from its dataset
  * files (data/metadata_MovingObstaclesNoRules.csv, data/risk_MovingObstaclesNoRules.csv). */
-static double oc_cri_core(double px, double py, double vx, double vy, int moving, double d, double b) {
+static double oc_cri_core(double px, double py, double vx, double vy, int moving, double d, double b, double aspect) {
     const double D1 = 32.0, D2 = 160.0, DA = 20.08, DB = 45.18;
     const double along = px * vx + py * vy;
     const double cross = px * vy - py * vx;
@@ -103,7 +103,8 @@ static double oc_cri_core(double px, double py, double vx, double vy, int moving
     const double bd = b * 57.29577951308232;
     const double q1 = (90.0 - bd) / 80.0, q2 = (bd + 270.0) / 225.0;
     const double u_b = bd < -45.0 ? q2 * q2 : (bd <= 10.0 ? 1.0 : (bd < 90.0 ? q1 * q1 : 0.0));
-    return (0.2 * u_b + ct) + 0.3 * u_d;
+    const double total = ((0.2 * u_b + ct) + 0.3 * u_d) + 0.2 * aspect;
+    return total > 0.0 ? total : 0.0;
 }
 
 /* oracle/auv_oracle.py: sincos */
@@ -148,20 +149,35 @@ static double oc_atan2(double y, double x) {
 static double oc_wrap(double a) { return a - floor((a + PI) * INV_TWO_PI) * TWO_PI; }
 
 /* oracle/ref_cri.py: risk_reference */
-static double oc_risk_reference(double mx, double my, double ovx, double ovy, double rvx, double rvy, double dist,
+static double oc_risk_reference(double mx, double my, double ovx, double ovy, double vox, double voy, double dist,
                                 double psi, double range) {
+    double sn, cs;
+    oc_sincos(psi, &sn, &cs);
+    const double ss = sqrt(vox * vox + voy * voy);
+    const double sx = ss * cs, sy = ss * sn;
     const double n = sqrt(mx * mx + my * my);
     const int has_n = n > 0.0;
     const double ns = has_n ? n : 1.0;
     const double ux = has_n ? mx / ns : 1.0, uy = has_n ? my / ns : 0.0;
-    const double vv = rvx * rvx + rvy * rvy;
     const int still = ovx == 0.0 && ovy == 0.0;
-    const double sp = sqrt(vv);
-    const double sps = vv > 0.0 ? sp : 1.0;
-    const double dvx = still ? (psi > 0.0 ? 1.0 : -1.0) : rvx / sps;
-    const double dvy = still ? 0.0 : rvy / sps;
+    const double so = sqrt(ovx * ovx + ovy * ovy);
+    const double sos = still ? 1.0 : so;
+    const double hx = ovx / sos, hy = ovy / sos;
+    const double dl = oc_atan2(ovy, ovx) - psi;
+    const int mirror = fabs(dl) > PI;
+    const double dot = sx * hx + sy * hy;
+    const double ex = mirror ? (2.0 * dot) * hx - sx : sx;
+    const double ey = mirror ? (2.0 * dot) * hy - sy : sy;
+    const double rx = ovx - ex, ry = ovy - ey;
+    const double rn = sqrt(rx * rx + ry * ry);
+    const double rns = rn > 0.0 ? rn : 1.0;
+    const double dvx = still ? (psi > 0.0 ? 1.0 : -1.0) : rx / rns;
+    const double dvy = still ? 0.0 : ry / rns;
+    const int moving = still ? ss > 0.0 : rn > 0.0;
+    const double ca = 0.0 - (ux * hx + uy * hy);
+    const double aspect = still ? 0.0 : ca * fabs(ca);
     const double b = oc_wrap(oc_atan2(my, mx) - psi);
-    const double r = oc_cri_core(dist * ux, dist * uy, dvx, dvy, vv > 0.0, dist, b);
+    const double r = oc_cri_core(dist * ux, dist * uy, dvx, dvy, moving, dist, b, aspect);
     return dist < range ? r : 0.0;
 }
 
@@ -364,7 +380,7 @@ static void oc_sense_env(const oc_config *cf, const oc_buffers *b, int e, int is
         const double term_c = (w_c * (fc * fc)) * (t_c / (t_c + tcpa));
         const double rr = term_d + (has_c ? term_c : 0.0);
         b->risk[(size_t)e * O + o] = cf->risk_model == 1
-            ? oc_risk_reference(mx, my, vx, vy, rvx, rvy, dist[o], psi, range) : (inrange ? rr : 0.0);
+            ? oc_risk_reference(mx, my, vx, vy, vox, voy, dist[o], psi, range) : (inrange ? rr : 0.0);
     }
 
     /* navigation, flags, reward */

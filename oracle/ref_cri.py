@@ -1,31 +1,38 @@
-"""The reference's collision-risk index for static obstacles (TEST INFRASTRUCTURE ONLY).
+"""The reference's collision-risk index (TEST INFRASTRUCTURE ONLY).
 
 The formula is not in the reference checkout; what is there are its inputs and
 outputs: data/metadata_MovingObstaclesNoRules.csv and
 data/risk_MovingObstaclesNoRules.csv, row-aligned, 23,680 per-obstacle records
 (layout: utils/explore_dataset.py:8,40-53; label reduction:
 utils/dataloader.py:104-120).  The restatement below was recovered from those
-records and reproduces every one of the 14,102 static-obstacle records
-(heading_ts == 0 and speed == speed_OS, utils/explore_dataset.py:46) to
-2e-15 (`tests/golden/cri_static_golden.npz`, `tests/test_ref_cri_cpu.py`).
-The 9,578 moving-obstacle records are NOT reproduced (their bearing and
-speed-ratio terms differ and were not recovered): for moving obstacles this
-index is an extrapolation and stays parity unpinned.
+records and reproduces ALL of them -- 14,102 static-obstacle records
+(heading_ts == 0 and speed == speed_OS, utils/explore_dataset.py:46) and 9,578
+moving-obstacle records -- to 2e-15 (`tests/golden/cri_golden.npz`,
+`tests/test_ref_cri_cpu.py`).
 
-    risk = 0.2 u_B(bearing) + 0.3 u_DCPA u_TCPA + 0.3 u_D(dist)
+    risk = max(0, 0.2 u_B(bearing) + 0.3 u_DCPA u_TCPA + 0.3 u_D(dist) + 0.2 u_A)
 
 * u_B: 1 for bearing in [-45, 10] deg; ((90 - b)/80)^2 on (10, 90);
   ((b + 270)/225)^2 below -45; 0 from 90 to 180.
 * The closest-point-of-approach pair uses the reference's own frames: the
   obstacle position p = dist * (cos, sin)(bearing + heading_OS), i.e. the body
   bearing turned into the world frame, against the unit direction (cos, sin) of
-  the logged relative course (for a static obstacle that course is 0 when
-  heading_OS > 0 and -pi otherwise).  With L = |p . v| and DCPA = |p x v|:
+  the logged relative course.  With L = |p . v| and DCPA = |p x v|:
   u_DCPA = 1 up to D1 = 32 m, linear to 0 at D2 = 160 m;
   closing (p . v < 0): t1 = sqrt(D1^2 - DCPA^2) (DCPA <= D1) else D1 - DCPA,
   t2 = sqrt(D2^2 - DCPA^2), u_TCPA = 1 for L <= t1, (t2 - L)/(t2 - t1) up to t2;
   opening: u_TCPA = 1 - L/D1.  The pair is 0 when the relative speed is 0.
 * u_D: 1 up to 20.08 m, ((45.18 - d)/25.1)^2 up to 45.18 m, 0 beyond.
+* u_A (moving obstacles only): cos(a)|cos(a)| of the vessel's bearing a seen
+  from the obstacle, relative to the obstacle's heading:
+  a = bearing + heading_OS + pi - heading_ts.  +1 dead ahead of the obstacle,
+  -1 dead astern.
+* The logged relative course (`reference_course`): a static obstacle has 0 when
+  heading_OS > 0 and -pi otherwise; a moving one has
+  heading_ts + atan2(s * speed_OS * sin D, speed_ts - speed_OS * cos D) with
+  D = heading_ts - heading_OS taken as is, s = +1 for |D| <= pi and -1 beyond
+  (the vessel's velocity mirrored about the obstacle's heading when the raw
+  difference leaves (-pi, pi]).  All 9,578 moving records follow it.
 
 Same arithmetic contract as `auv_oracle.py` (binary64, unfused, this operation
 order, `sincos` / `atan2` of the contract), so the HIP and C implementations
@@ -35,7 +42,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .auv_oracle import sincos, atan2, wrap_angle
+from .auv_oracle import PI, sincos, atan2, wrap_angle
 
 RAD2DEG = 57.29577951308232
 CRI_D1 = 32.0
@@ -45,6 +52,7 @@ CRI_DB = 45.18
 CRI_W_B = 0.2
 CRI_W_CT = 0.3
 CRI_W_D = 0.3
+CRI_W_A = 0.2
 
 
 def bearing_membership(b):
@@ -56,9 +64,10 @@ def bearing_membership(b):
                              np.where(bd < 90.0, q1 * q1, 0.0)))
 
 
-def cri_core(px, py, vx, vy, moving, d, b):
+def cri_core(px, py, vx, vy, moving, d, b, aspect):
     """px, py: obstacle position; vx, vy: unit relative-course direction;
-    moving: relative speed > 0; d: surface distance; b: body bearing (rad)."""
+    moving: relative speed > 0; d: surface distance; b: body bearing (rad);
+    aspect: u_A (0 for a static obstacle)."""
     along = px * vx + py * vy
     cross = px * vy - py * vx
     dc = np.abs(cross)
@@ -75,60 +84,94 @@ def cri_core(px, py, vx, vy, moving, d, b):
     ct = np.where(moving, (CRI_W_CT * u_dc) * u_t, 0.0)
     qd = np.maximum((CRI_DB - d) / (CRI_DB - CRI_DA), 0.0)
     u_d = np.where(d <= CRI_DA, 1.0, qd * qd)
-    return (CRI_W_B * bearing_membership(b) + ct) + CRI_W_D * u_d
+    total = ((CRI_W_B * bearing_membership(b) + ct) + CRI_W_D * u_d) + CRI_W_A * aspect
+    return np.maximum(total, 0.0)
 
 
-def cri_rows(own_heading, dist, rel_speed, bearing, course):
-    """Risk of dataset records: one value per (heading_OS, dist, speed, bearing, course)."""
+def cri_rows(own_speed, own_heading, heading_ts, dist, rel_speed, bearing, course):
+    """Risk of dataset records: one value per obstacle record (speed_OS,
+    heading_OS | heading_ts, dist, speed, bearing, course) of a metadata row."""
+    own_speed = np.asarray(own_speed, dtype=np.float64)
     own_heading = np.asarray(own_heading, dtype=np.float64)
+    heading_ts = np.asarray(heading_ts, dtype=np.float64)
     dist = np.asarray(dist, dtype=np.float64)
-    sw, cw = sincos(np.asarray(bearing, dtype=np.float64) + own_heading)
+    rel_speed = np.asarray(rel_speed, dtype=np.float64)
+    bearing = np.asarray(bearing, dtype=np.float64)
+    bw = bearing + own_heading
+    sw, cw = sincos(bw)
     sc, cc = sincos(np.asarray(course, dtype=np.float64))
-    return cri_core(dist * cw, dist * sw, cc, sc, np.asarray(rel_speed) > 0.0, dist, bearing)
+    static = (heading_ts == 0.0) & (rel_speed == own_speed)       # utils/explore_dataset.py:46
+    _, ca = sincos(bw - heading_ts)                                # cos(a) = -cos(a - pi)
+    aspect = np.where(static, 0.0, 0.0 - ca * np.abs(ca))
+    return cri_core(dist * cw, dist * sw, cc, sc, rel_speed > 0.0, dist, bearing, aspect)
+
+
+def reference_course(own_speed, own_heading, heading_ts, speed_ts):
+    """The relative course the reference logs for a moving obstacle (rad, not wrapped)."""
+    dl = heading_ts - own_heading
+    s = np.where(np.abs(dl) > np.pi, -1.0, 1.0)
+    return heading_ts + np.arctan2(s * own_speed * np.sin(dl), speed_ts - own_speed * np.cos(dl))
 
 
 def risk_reference(state, circles, poly_pose, dist, sensor_range):
     """Per-obstacle risk [V, C+P] of a simulator state with the index above.
 
-    Obstacles that do not move take the reference's static-obstacle course
-    (0 / -pi by the sign of the vessel's heading); moving ones take the
-    direction of their velocity relative to the vessel (extrapolation, see the
-    module docstring).  p is the hull distance along the direction of the
-    obstacle's centre; 0 outside sensor range."""
-    V = state.shape[1]
+    The inputs of the index are formed the way the reference forms them: the
+    vessel's velocity is its speed along its heading; an obstacle without a
+    velocity takes the static course (+x when the heading is positive, -x
+    otherwise) and no aspect term; an obstacle with a velocity is headed along
+    it, and the relative course is its velocity minus the vessel's, the latter
+    mirrored about the obstacle's heading when heading_ts - heading_OS leaves
+    (-pi, pi].  p is the hull distance along the direction of the obstacle's
+    centre; 0 outside sensor range."""
     C = circles.shape[1]
     P = poly_pose.shape[1]
+    V = state.shape[1]
     px, py, psi, u, v = state[0], state[1], state[2], state[3], state[4]
     s, c = sincos(psi)
     vox = c * u - s * v
     voy = s * u + c * v
+    ss = np.sqrt(vox * vox + voy * voy)
+    sx = ss * c
+    sy = ss * s
     risk = np.zeros((V, C + P), dtype=np.float64)
     for o in range(C + P):
         if o < C:
             cx, cy = circles[:, o, 0], circles[:, o, 1]
-            vx, vy = circles[:, o, 3], circles[:, o, 4]
+            ovx, ovy = circles[:, o, 3], circles[:, o, 4]
         else:
             k = o - C
             cx, cy = poly_pose[:, k, 0], poly_pose[:, k, 1]
-            vx, vy = poly_pose[:, k, 4], poly_pose[:, k, 5]
+            ovx, ovy = poly_pose[:, k, 4], poly_pose[:, k, 5]
         mx = cx - px
         my = cy - py
-        rvx = vx - vox
-        rvy = vy - voy
         d = dist[:, o]
         n = np.sqrt(mx * mx + my * my)
         has_n = n > 0.0
         ns = np.where(has_n, n, 1.0)
         ux = np.where(has_n, mx / ns, 1.0)
         uy = np.where(has_n, my / ns, 0.0)
-        vv = rvx * rvx + rvy * rvy
-        still = (vx == 0.0) & (vy == 0.0)
-        sp = np.sqrt(vv)
-        sps = np.where(vv > 0.0, sp, 1.0)
-        dvx = np.where(still, np.where(psi > 0.0, 1.0, -1.0), rvx / sps)
-        dvy = np.where(still, 0.0, rvy / sps)
+        still = (ovx == 0.0) & (ovy == 0.0)
+        so = np.sqrt(ovx * ovx + ovy * ovy)
+        sos = np.where(still, 1.0, so)
+        hx = ovx / sos
+        hy = ovy / sos
+        dl = atan2(ovy, ovx) - psi
+        mirror = np.abs(dl) > PI
+        dot = sx * hx + sy * hy
+        ex = np.where(mirror, (2.0 * dot) * hx - sx, sx)
+        ey = np.where(mirror, (2.0 * dot) * hy - sy, sy)
+        rx = ovx - ex
+        ry = ovy - ey
+        rn = np.sqrt(rx * rx + ry * ry)
+        rns = np.where(rn > 0.0, rn, 1.0)
+        dvx = np.where(still, np.where(psi > 0.0, 1.0, -1.0), rx / rns)
+        dvy = np.where(still, 0.0, ry / rns)
+        moving = np.where(still, ss > 0.0, rn > 0.0)
+        ca = 0.0 - (ux * hx + uy * hy)
+        aspect = np.where(still, 0.0, ca * np.abs(ca))
         b = wrap_angle(atan2(my, mx) - psi)
         with np.errstate(invalid="ignore"):   # absent slots have d = +inf; they are gated to 0
-            r = cri_core(d * ux, d * uy, dvx, dvy, vv > 0.0, d, b)
+            r = cri_core(d * ux, d * uy, dvx, dvy, moving, d, b, aspect)
         risk[:, o] = np.where(d < sensor_range, r, 0.0)
     return risk

@@ -1,9 +1,10 @@
-"""The reference's risk index for static obstacles, pinned by the reference's
-own dataset: `cri_static_golden.npz` holds every static-obstacle record of
-data/metadata_MovingObstaclesNoRules.csv with the risk data/risk_MovingObstaclesNoRules.csv
-logged for it (tests/golden/make_cri_golden.py).  The oracle restatement has to
-reproduce all of them; the C restatement has to equal the numpy one bit for bit
-inside a simulation."""
+"""The reference's risk index, pinned by the reference's own dataset:
+`cri_golden.npz` holds every per-obstacle record of
+data/metadata_MovingObstaclesNoRules.csv with the risk
+data/risk_MovingObstaclesNoRules.csv logged for it (23,680 records;
+tests/golden/make_cri_golden.py).  The oracle restatement has to reproduce all
+of them, in both of its forms (dataset records, simulator state); the C
+restatement has to equal the numpy one bit for bit inside a simulation."""
 import os
 
 import numpy as np
@@ -12,23 +13,88 @@ from gym_auv_amd import params, scenarios
 from oracle import c_oracle, ref_cri
 from tests.helpers import PAIRS, make_oracle, same_bits
 
-GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "cri_static_golden.npz")
-TOL = 2e-15   # the reference's own operation order is unknown; 14,102 records agree to 1.1e-15
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "cri_golden.npz")
+TOL = 2e-15   # the reference's own operation order is unknown; all records agree to 1.1e-15
 
 
-def test_oracle_reproduces_every_static_record_of_the_reference():
+def _static(g):
+    return (g["heading_ts"] == 0.0) & (g["rel_speed"] == g["own_speed"])     # utils/explore_dataset.py:46
+
+
+def test_oracle_reproduces_every_record_of_the_reference():
     g = np.load(GOLDEN)
-    assert len(g["risk"]) == 14102
-    got = ref_cri.cri_rows(g["own_heading"], g["dist"], g["rel_speed"], g["bearing"], g["course"])
+    assert len(g["risk"]) == 23680 and int(_static(g).sum()) == 14102
+    got = ref_cri.cri_rows(g["own_speed"], g["own_heading"], g["heading_ts"], g["dist"], g["rel_speed"],
+                           g["bearing"], g["course"])
     err = np.abs(got - g["risk"])
     assert err.max() <= TOL, f"max |oracle - reference| = {err.max()} at record {int(err.argmax())}"
     # the records cover every branch of the index
-    assert (g["risk"] == 0.0).sum() > 100 and (g["risk"] == 0.2).sum() > 100 and (g["risk"] == 0.6).sum() > 10
-    assert g["dist"].min() < 20.08 and g["dist"].max() > 160.0
-    assert (g["rel_speed"] == 0.0).sum() > 50      # vessel at rest: no CPA term
+    st = _static(g)
+    assert (g["risk"][st] == 0.0).sum() > 100 and (g["risk"][st] == 0.2).sum() > 100
+    assert (g["risk"][st] == 0.6).sum() > 10
+    assert (g["risk"][~st] == 0.0).sum() > 1000           # clipped at 0 by the aspect term
+    assert g["risk"].max() > 0.99                          # all four terms saturated
+    assert g["dist"].min() < 0.0 and g["dist"].max() > 160.0
+    assert (g["rel_speed"] == 0.0).sum() > 50              # vessel at rest: no CPA term
     # the reference's static-obstacle course is 0 / -pi by the sign of the heading
-    assert np.array_equal(g["course"] == 0.0, g["own_heading"] > 0.0)
-    assert set(np.unique(g["course"])) == {0.0, -np.pi}
+    assert np.array_equal(g["course"][st] == 0.0, g["own_heading"][st] > 0.0)
+    assert set(np.unique(g["course"][st])) == {0.0, -np.pi}
+
+
+def _target_speed(g):
+    """speed_ts of the moving records, from the law of cosines the files obey;
+    of its two roots the one whose `reference_course` is the logged course."""
+    dl = g["heading_ts"] - g["own_heading"]
+    cd = np.cos(dl)
+    disc = np.sqrt(np.clip(g["rel_speed"] ** 2 - g["own_speed"] ** 2 * (1.0 - cd * cd), 0.0, None))
+    best, err = None, None
+    for so in (g["own_speed"] * cd + disc, g["own_speed"] * cd - disc):
+        c = ref_cri.reference_course(g["own_speed"], g["own_heading"], g["heading_ts"], so)
+        e = np.abs(np.mod(c - g["course"] + np.pi, 2 * np.pi) - np.pi)
+        if best is None:
+            best, err = so.copy(), e
+        else:
+            take = e < err
+            best[take], err[take] = so[take], e[take]
+    return best, err
+
+
+def test_relative_course_rule_of_the_moving_records():
+    g = np.load(GOLDEN)
+    mv = ~_static(g)
+    so, err = _target_speed(g)
+    assert err[mv].max() < 1e-9
+    raw = np.abs(g["heading_ts"] - g["own_heading"])[mv]
+    assert (raw > np.pi).sum() > 2000 and (raw <= np.pi).sum() > 2000     # both branches are in the files
+
+
+def test_state_form_reproduces_the_reference_too():
+    """`risk_reference` (the form the simulation uses) on states rebuilt from
+    the records: vessel at the origin with speed_OS along heading_OS, the
+    obstacle `dist` away on the logged bearing, moving with speed_ts along
+    heading_ts.  It derives course, aspect and bearing itself."""
+    g = np.load(GOLDEN)
+    st = _static(g)
+    so, _ = _target_speed(g)
+    so = np.where(st, 0.0, so)
+    keep = st | (so > 1e-9)
+    n = int(keep.sum())
+    assert n > 23000
+    state = np.zeros((6, n))
+    state[2] = g["own_heading"][keep]
+    state[3] = g["own_speed"][keep]
+    bw = g["bearing"][keep] + g["own_heading"][keep]
+    circles = np.zeros((n, 1, 5))
+    circles[:, 0, 0] = 100.0 * np.cos(bw)          # direction only: the hull distance is passed separately
+    circles[:, 0, 1] = 100.0 * np.sin(bw)
+    circles[:, 0, 2] = 1.0
+    circles[:, 0, 3] = so[keep] * np.cos(g["heading_ts"][keep])
+    circles[:, 0, 4] = so[keep] * np.sin(g["heading_ts"][keep])
+    dist = g["dist"][keep][:, None]
+    got = ref_cri.risk_reference(state, circles, np.zeros((n, 0, 6)), dist, np.inf)[:, 0]
+    err = np.abs(got - g["risk"][keep])
+    # looser than the record form: bearing, course and speed_ts are recomputed here
+    assert err.max() < 1e-9, f"max {err.max()} at {int(err.argmax())}"
 
 
 def test_bearing_membership_shape():
@@ -46,18 +112,18 @@ def test_bearing_membership_shape():
 
 
 def test_index_limits():
+    one = np.array(1.0)
+    core = ref_cri.cri_core
     # astern, far away, opening: nothing
-    z = ref_cri.cri_core(np.array(200.0), np.array(0.0), np.array(1.0), np.array(0.0), np.array(True),
-                         np.array(200.0), np.array(3.0))
-    assert float(z) == 0.0
-    # dead ahead on the bow at 10 m, closing: all three terms saturate
-    z = ref_cri.cri_core(np.array(-10.0), np.array(0.0), np.array(1.0), np.array(0.0), np.array(True),
-                         np.array(10.0), np.array(0.0))
-    assert abs(float(z) - 0.8) < 1e-15
+    assert float(core(200.0 * one, 0 * one, one, 0 * one, np.array(True), 200.0 * one, 3.0 * one, 0 * one)) == 0.0
+    # dead ahead on the bow at 10 m, closing, static: three terms saturate
+    assert abs(float(core(-10.0 * one, 0 * one, one, 0 * one, np.array(True), 10.0 * one, 0 * one, 0 * one)) - 0.8) < 1e-15
     # same, vessel at rest: no CPA term
-    z = ref_cri.cri_core(np.array(-10.0), np.array(0.0), np.array(1.0), np.array(0.0), np.array(False),
-                         np.array(10.0), np.array(0.0))
-    assert abs(float(z) - 0.5) < 1e-15
+    assert abs(float(core(-10.0 * one, 0 * one, one, 0 * one, np.array(False), 10.0 * one, 0 * one, 0 * one)) - 0.5) < 1e-15
+    # a moving obstacle heading straight at the vessel adds the aspect term: 1.0
+    assert abs(float(core(-10.0 * one, 0 * one, one, 0 * one, np.array(True), 10.0 * one, 0 * one, one)) - 1.0) < 1e-15
+    # one sailing away from far off: clipped at 0, not negative
+    assert float(core(200.0 * one, 0 * one, one, 0 * one, np.array(True), 200.0 * one, 3.0 * one, -one)) == 0.0
 
 
 def _pair(cfg, scene):
@@ -73,7 +139,7 @@ def test_c_oracle_equals_numpy_oracle_with_the_reference_index():
     cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=203)
     cfg = dict(cfg, risk_model=1)
     scene["circles"][::2, 1::2, 2] = 0.0       # absent slots
-    scene["circles"][1::4, 0, 3:5] = 0.3       # a circle that moves: takes the relative-velocity course
+    scene["circles"][1::4, 0, 3:5] = 0.3       # a circle that moves
     scene["poly_nv"][::3, ::2] = 0
     env, cenv = _pair(cfg, scene)
     env.reset(scene["init_state"])
@@ -81,6 +147,7 @@ def test_c_oracle_equals_numpy_oracle_with_the_reference_index():
     acts = scenarios.random_actions(203, 15, seed=5)
     default = make_oracle(dict(cfg, risk_model=0), scene)
     default.reset(scene["init_state"])
+    mirrored = 0
     for k in range(15):
         env.step(acts[k])
         cenv.step(acts[k])
@@ -88,6 +155,9 @@ def test_c_oracle_equals_numpy_oracle_with_the_reference_index():
         bad = [n for n, a in PAIRS.items() if a != "episode" and not same_bits(
             np.asarray(getattr(cenv, a)).reshape(np.shape(getattr(env, a))), getattr(env, a))]
         assert not bad, f"C oracle != numpy oracle after step {k + 1}: {bad}"
+        ht = np.arctan2(env.poly_pose[:, :, 5], env.poly_pose[:, :, 4])
+        mirrored += int((np.abs(ht - env.state[2][:, None]) > np.pi).sum())
+    assert mirrored > 100                                       # the mirrored-course branch is exercised
     assert env.risk.max() > 0.2 and env.risk.max() <= 1.0 and env.risk.min() >= 0.0
     assert not np.array_equal(env.risk, default.risk)          # the option does select another index
     assert np.array_equal(env.ranges, default.ranges)          # and nothing else

@@ -1,9 +1,9 @@
 """The reference's risk index on the GPU, through the C ABI.
 
-* `auv_risk_rows` on every static-obstacle record of the reference's dataset
-  (`cri_static_golden.npz`, tests/golden/make_cri_golden.py): within 2e-15 of
-  the value the reference logged (its operation order is unknown, so not bit
-  for bit) and bit-equal to the oracle restatement.
+* `auv_risk_rows` on every per-obstacle record of the reference's dataset
+  (`cri_golden.npz`, 23,680 records, tests/golden/make_cri_golden.py): within
+  2e-15 of the value the reference logged (its operation order is unknown, so
+  not bit for bit) and bit-equal to the oracle restatement.
 * `AUV_OPT_RISK_MODEL = AUV_RISK_REFERENCE` inside the simulation, both LiDAR
   paths: every buffer bit-equal to the oracle with the same index."""
 import os
@@ -18,14 +18,15 @@ from tests.helpers import assert_all_equal, make_oracle, make_sim
 
 pytestmark = pytest.mark.gpu
 
-GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "cri_static_golden.npz")
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "cri_golden.npz")
 TOL = 2e-15
+COLS = ("own_speed", "own_heading", "heading_ts", "dist", "rel_speed", "bearing", "course")
 
 
 def _rows(sim, g, sl=slice(None)):
     dev = torch.device("cuda", sim.device)
     cols = [torch.from_numpy(np.ascontiguousarray(g[k][sl])).to(dev)
-            for k in ("own_heading", "dist", "rel_speed", "bearing", "course")]
+            for k in COLS]
     out = sim.risk_rows(*cols)
     torch.cuda.synchronize(dev)
     return out.cpu().numpy()
@@ -36,10 +37,10 @@ def test_risk_rows_reproduce_the_reference_dataset():
     sim = make_sim(cfg, scene)
     g = np.load(GOLDEN)
     got = _rows(sim, g)
-    assert got.shape == (14102,)
+    assert got.shape == (23680,)
     err = np.abs(got - g["risk"])
     assert err.max() <= TOL, f"max |device - reference| = {err.max()} at record {int(err.argmax())}"
-    want = ref_cri.cri_rows(g["own_heading"], g["dist"], g["rel_speed"], g["bearing"], g["course"])
+    want = ref_cri.cri_rows(*[g[k] for k in COLS])
     assert np.array_equal(got, want), f"{int((got != want).sum())} records differ from the oracle"
     # ragged sizes: empty, one record, a non-multiple of the workgroup
     assert _rows(sim, g, slice(0, 0)).shape == (0,)
@@ -53,9 +54,9 @@ def test_risk_rows_rejects_bad_arguments():
     sim = make_sim(cfg, scene)
     x = torch.zeros(4, dtype=torch.float64, device="cuda")
     with pytest.raises(ValueError):
-        sim.risk_rows(x, x, x, x, x[:3])
+        sim.risk_rows(x, x, x, x, x, x, x[:3])
     with pytest.raises(TypeError):
-        sim.risk_rows(x, x, x, x, x.float())
+        sim.risk_rows(x, x, x, x, x, x, x.float())
     with pytest.raises(_lib.AuvError):
         sim.set_option(_lib.OPT_RISK_MODEL, 7)
     sim.close()
