@@ -7,10 +7,12 @@ and observation assembly.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` may import it; the product path never
 does.
 
-PARITY UNPINNED for dynamics, obstacle advance, LiDAR, collision and risk:
-the reference checkout (hebe2602/gym-auv @ v1) does not contain the simulator
-(`radarCNN.py:232` only names the absent ``gym_auv/`` package), so there is no
-reference function, golden vector or fixture to pin these against.  What the
+PARITY UNPINNED for dynamics, obstacle advance, LiDAR, collision and the
+default risk index: the reference checkout (hebe2602/gym-auv @ v1) does not
+contain the simulator (`radarCNN.py:232` only names the absent ``gym_auv/``
+package), so there is no reference function, golden vector or fixture to pin
+these against.  (The reference's own risk index, `ref_cri.py`, IS pinned: by
+every record of the reference's dataset files.)  What the
 mounted files do constrain is restated here with citations:
 
 * scan width 180 and maximum range 150 m          -> utils/dataloader.py:13,56,127
