@@ -345,11 +345,19 @@ __global__ __launch_bounds__(256) void k_encounter(EncArgs a) {
         a.obst_dist[eo] = dist;
         lds_dist[i] = dist;
         double* m = a.meta + eo * 5;
-        m[0] = hd;
         m[1] = dist;
-        m[2] = __builtin_sqrt(vv);
         m[3] = wrap_angle(atan2_det(my, mx) - psi);
-        m[4] = wrap_angle(atan2_det(rvy, rvx) - psi);
+        if (a.risk_model == 1) {
+            // speed, heading and course columns follow the reference's conventions
+            const RefMotion rm = reference_motion(vx, vy, vox, voy, psi);
+            m[0] = rm.still ? 0.0 : rm.heading;
+            m[2] = rm.speed;
+            m[4] = rm.course;
+        } else {
+            m[0] = hd;
+            m[2] = __builtin_sqrt(vv);
+            m[4] = wrap_angle(atan2_det(rvy, rvx) - psi);
+        }
         // default risk index
         const double R = a.sensor_range;
         const double d = dist < 0.0 ? 0.0 : dist;

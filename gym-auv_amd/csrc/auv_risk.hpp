@@ -58,47 +58,63 @@ __device__ __forceinline__ double cri_core(double px, double py, double vx, doub
     return total > 0.0 ? total : 0.0;
 }
 
-// One obstacle of a simulator state, its inputs formed the way the reference
-// forms them: m = centre relative to the vessel, (ovx, ovy) the obstacle's
-// velocity, (vox, voy) the vessel's, dist the signed hull distance, psi the
-// vessel's heading.  The vessel's velocity is taken as its speed along its
-// heading.  An obstacle without a velocity has the static course (+x for a
-// positive heading, -x otherwise) and no aspect term; one with a velocity is
-// headed along it, and the relative course is its velocity minus the
-// vessel's, the latter mirrored about the obstacle's heading when
-// heading_ts - heading_OS leaves (-pi, pi].
-__device__ __forceinline__ double risk_reference(double mx, double my, double ovx, double ovy, double vox, double voy,
-                                                 double dist, double psi, double range) {
+// The relative motion of one obstacle the way the reference forms it: the
+// vessel's velocity is its speed along its heading; an obstacle without a
+// velocity is static (course 0 for a positive heading, -pi otherwise, relative
+// speed = the vessel's speed); one with a velocity is headed along it, and its
+// relative velocity is its own minus the vessel's, the latter mirrored about
+// the obstacle's heading when heading_ts - heading_OS leaves (-pi, pi].
+struct RefMotion {
+    bool still;      // obstacle without a velocity
+    double hx, hy;   // unit heading of a moving obstacle
+    double heading;  // heading_ts: atan2 of its velocity, 0 when still
+    double rx, ry;   // relative velocity (moving obstacle)
+    double speed;    // relative speed
+    double course;   // logged relative course, (-pi, pi]
+};
+
+__device__ __forceinline__ RefMotion reference_motion(double ovx, double ovy, double vox, double voy, double psi) {
+    RefMotion m;
     const SinCos sc = sincos_det(psi);
     const double ss = __builtin_sqrt(vox * vox + voy * voy);
     const double sx = ss * sc.c;
     const double sy = ss * sc.s;
+    m.still = ovx == 0.0 && ovy == 0.0;
+    const double so = __builtin_sqrt(ovx * ovx + ovy * ovy);
+    const double sos = m.still ? 1.0 : so;
+    m.hx = ovx / sos;
+    m.hy = ovy / sos;
+    m.heading = atan2_det(ovy, ovx);
+    const bool mirror = __builtin_fabs(m.heading - psi) > kPi;
+    const double dot = sx * m.hx + sy * m.hy;
+    const double ex = mirror ? (2.0 * dot) * m.hx - sx : sx;
+    const double ey = mirror ? (2.0 * dot) * m.hy - sy : sy;
+    m.rx = ovx - ex;
+    m.ry = ovy - ey;
+    const double rn = __builtin_sqrt(m.rx * m.rx + m.ry * m.ry);
+    m.speed = m.still ? ss : rn;
+    m.course = m.still ? (psi > 0.0 ? 0.0 : 0.0 - kPi) : atan2_det(m.ry, m.rx);
+    return m;
+}
+
+// One obstacle of a simulator state: m = centre relative to the vessel, (ovx,
+// ovy) the obstacle's velocity, (vox, voy) the vessel's, dist the signed hull
+// distance, psi the vessel's heading.
+__device__ __forceinline__ double risk_reference(double mx, double my, double ovx, double ovy, double vox, double voy,
+                                                 double dist, double psi, double range) {
+    const RefMotion rm = reference_motion(ovx, ovy, vox, voy, psi);
     const double n = __builtin_sqrt(mx * mx + my * my);
     const bool has_n = n > 0.0;
     const double ns = has_n ? n : 1.0;
     const double ux = has_n ? mx / ns : 1.0;
     const double uy = has_n ? my / ns : 0.0;
-    const bool still = ovx == 0.0 && ovy == 0.0;
-    const double so = __builtin_sqrt(ovx * ovx + ovy * ovy);
-    const double sos = still ? 1.0 : so;
-    const double hx = ovx / sos;
-    const double hy = ovy / sos;
-    const double dl = atan2_det(ovy, ovx) - psi;
-    const bool mirror = __builtin_fabs(dl) > kPi;
-    const double dot = sx * hx + sy * hy;
-    const double ex = mirror ? (2.0 * dot) * hx - sx : sx;
-    const double ey = mirror ? (2.0 * dot) * hy - sy : sy;
-    const double rx = ovx - ex;
-    const double ry = ovy - ey;
-    const double rn = __builtin_sqrt(rx * rx + ry * ry);
-    const double rns = rn > 0.0 ? rn : 1.0;
-    const double dvx = still ? (psi > 0.0 ? 1.0 : -1.0) : rx / rns;
-    const double dvy = still ? 0.0 : ry / rns;
-    const bool moving = still ? ss > 0.0 : rn > 0.0;
-    const double ca = 0.0 - (ux * hx + uy * hy);
-    const double aspect = still ? 0.0 : ca * __builtin_fabs(ca);
+    const double rns = rm.speed > 0.0 ? rm.speed : 1.0;
+    const double dvx = rm.still ? (psi > 0.0 ? 1.0 : -1.0) : rm.rx / rns;
+    const double dvy = rm.still ? 0.0 : rm.ry / rns;
+    const double ca = 0.0 - (ux * rm.hx + uy * rm.hy);
+    const double aspect = rm.still ? 0.0 : ca * __builtin_fabs(ca);
     const double b = wrap_angle(atan2_det(my, mx) - psi);
-    const double r = cri_core(dist * ux, dist * uy, dvx, dvy, moving, dist, b, aspect);
+    const double r = cri_core(dist * ux, dist * uy, dvx, dvy, rm.speed > 0.0, dist, b, aspect);
     return dist < range ? r : 0.0;
 }
 

@@ -646,6 +646,13 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
                     const double mx = ob[OB_MX * ob_n], my = ob[OB_MY * ob_n], rvx = ob[OB_RVX * ob_n], rvy = ob[OB_RVY * ob_n];
                     const size_t eo = (size_t)e * O + o;
                     double* m = a.meta + eo * 5;
+                    // RISK == 1: speed, heading and course columns follow the reference's conventions
+                    auto ref_motion = [&]() -> RefMotion {
+                        const double* ov = o < C ? a.circles + ((size_t)e * C + o) * 5 + 3
+                                                 : a.poly_pose + ((size_t)e * P + (o - C)) * 6 + 4;
+                        const double* er = a.envrec + (size_t)e * ER_COUNT;
+                        return reference_motion(ov[0], ov[1], er[ER_VOX], er[ER_VOY], a.state[2 * (size_t)V + e]);
+                    };
                     if (task == 0) {
                         dist = hull_distance(ob, el, o);
                         double hd = 0.0;
@@ -660,9 +667,15 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
                             hd = pb[PB_HEADING * pb_n];
                         }
                         a.obst_dist[eo] = dist;
-                        m[0] = hd;
                         m[1] = dist;
-                        m[2] = __builtin_sqrt(rvx * rvx + rvy * rvy);
+                        if (RISK == 1) {
+                            const RefMotion rm = ref_motion();
+                            m[0] = rm.still ? 0.0 : rm.heading;
+                            m[2] = rm.speed;
+                        } else {
+                            m[0] = hd;
+                            m[2] = __builtin_sqrt(rvx * rvx + rvy * rvy);
+                        }
                     } else if (task == 3) {
                         if (RISK == 1) {
                             const double* ov = o < C ? a.circles + ((size_t)e * C + o) * 5 + 3
@@ -674,6 +687,8 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
                             a.risk[eo] = risk_index(mx, my, rvx, rvy, rvx * rvx + rvy * rvy, hull_distance(ob, el, o), range,
                                                     a.inv_range, a.w_d, a.w_c, a.t_c);
                         }
+                    } else if (RISK == 1 && task == 2) {
+                        m[4] = ref_motion().course;
                     } else {
                         const double psi = a.state[2 * (size_t)V + e];
                         m[2 + task] = wrap_angle(atan2_det(task == 1 ? my : rvy, task == 1 ? mx : rvx) - psi);

@@ -129,7 +129,12 @@ typedef enum auv_option {
                                * index as recovered from data/metadata_MovingObstaclesNoRules.csv against
                                * data/risk_MovingObstaclesNoRules.csv (0.2 bearing + 0.3 DCPA x TCPA + 0.3 range
                                * + 0.2 target-aspect memberships, clipped at 0, in the reference's frames); it
-                               * reproduces all 23,680 per-obstacle records of those files to 2e-15. */
+                               * reproduces all 23,680 per-obstacle records of those files to 2e-15.  With it
+                               * the heading_ts, speed and course fields of AUV_BUF_META follow the reference's
+                               * conventions too (heading_ts = direction of the obstacle's velocity, 0 at rest;
+                               * course = world-frame direction of the relative velocity as the reference forms
+                               * it, 0 / -pi for an obstacle at rest), so that auv_risk_rows of a metadata row
+                               * gives back the AUV_BUF_RISK row, as in the reference's files. */
 } auv_option;
 #define AUV_LIDAR_RASTER 0
 #define AUV_LIDAR_ALL_PAIRS 1

@@ -148,36 +148,47 @@ static double oc_atan2(double y, double x) {
 
 static double oc_wrap(double a) { return a - floor((a + PI) * INV_TWO_PI) * TWO_PI; }
 
-/* oracle/ref_cri.py: risk_reference */
-static double oc_risk_reference(double mx, double my, double ovx, double ovy, double vox, double voy, double dist,
-                                double psi, double range) {
+/* oracle/ref_cri.py: reference_motion */
+typedef struct { int still; double hx, hy, heading, rx, ry, speed, course; } oc_ref_motion;
+static oc_ref_motion oc_reference_motion(double ovx, double ovy, double vox, double voy, double psi) {
+    oc_ref_motion m;
     double sn, cs;
     oc_sincos(psi, &sn, &cs);
     const double ss = sqrt(vox * vox + voy * voy);
     const double sx = ss * cs, sy = ss * sn;
+    m.still = ovx == 0.0 && ovy == 0.0;
+    const double so = sqrt(ovx * ovx + ovy * ovy);
+    const double sos = m.still ? 1.0 : so;
+    m.hx = ovx / sos;
+    m.hy = ovy / sos;
+    m.heading = oc_atan2(ovy, ovx);
+    const int mirror = fabs(m.heading - psi) > PI;
+    const double dot = sx * m.hx + sy * m.hy;
+    const double ex = mirror ? (2.0 * dot) * m.hx - sx : sx;
+    const double ey = mirror ? (2.0 * dot) * m.hy - sy : sy;
+    m.rx = ovx - ex;
+    m.ry = ovy - ey;
+    const double rn = sqrt(m.rx * m.rx + m.ry * m.ry);
+    m.speed = m.still ? ss : rn;
+    m.course = m.still ? (psi > 0.0 ? 0.0 : 0.0 - PI) : oc_atan2(m.ry, m.rx);
+    return m;
+}
+
+/* oracle/ref_cri.py: risk_reference */
+static double oc_risk_reference(double mx, double my, double ovx, double ovy, double vox, double voy, double dist,
+                                double psi, double range) {
+    const oc_ref_motion rm = oc_reference_motion(ovx, ovy, vox, voy, psi);
     const double n = sqrt(mx * mx + my * my);
     const int has_n = n > 0.0;
     const double ns = has_n ? n : 1.0;
     const double ux = has_n ? mx / ns : 1.0, uy = has_n ? my / ns : 0.0;
-    const int still = ovx == 0.0 && ovy == 0.0;
-    const double so = sqrt(ovx * ovx + ovy * ovy);
-    const double sos = still ? 1.0 : so;
-    const double hx = ovx / sos, hy = ovy / sos;
-    const double dl = oc_atan2(ovy, ovx) - psi;
-    const int mirror = fabs(dl) > PI;
-    const double dot = sx * hx + sy * hy;
-    const double ex = mirror ? (2.0 * dot) * hx - sx : sx;
-    const double ey = mirror ? (2.0 * dot) * hy - sy : sy;
-    const double rx = ovx - ex, ry = ovy - ey;
-    const double rn = sqrt(rx * rx + ry * ry);
-    const double rns = rn > 0.0 ? rn : 1.0;
-    const double dvx = still ? (psi > 0.0 ? 1.0 : -1.0) : rx / rns;
-    const double dvy = still ? 0.0 : ry / rns;
-    const int moving = still ? ss > 0.0 : rn > 0.0;
-    const double ca = 0.0 - (ux * hx + uy * hy);
-    const double aspect = still ? 0.0 : ca * fabs(ca);
+    const double rns = rm.speed > 0.0 ? rm.speed : 1.0;
+    const double dvx = rm.still ? (psi > 0.0 ? 1.0 : -1.0) : rm.rx / rns;
+    const double dvy = rm.still ? 0.0 : rm.ry / rns;
+    const double ca = 0.0 - (ux * rm.hx + uy * rm.hy);
+    const double aspect = rm.still ? 0.0 : ca * fabs(ca);
     const double b = oc_wrap(oc_atan2(my, mx) - psi);
-    const double r = oc_cri_core(dist * ux, dist * uy, dvx, dvy, moving, dist, b, aspect);
+    const double r = oc_cri_core(dist * ux, dist * uy, dvx, dvy, rm.speed > 0.0, dist, b, aspect);
     return dist < range ? r : 0.0;
 }
 
@@ -366,6 +377,12 @@ static void oc_sense_env(const oc_config *cf, const oc_buffers *b, int e, int is
         m[2] = sqrt(rvx * rvx + rvy * rvy);
         m[3] = oc_wrap(oc_atan2(my, mx) - psi);
         m[4] = oc_wrap(oc_atan2(rvy, rvx) - psi);
+        if (cf->risk_model == 1) { /* oracle/ref_cri.py: reference_metadata */
+            const oc_ref_motion rm = oc_reference_motion(vx, vy, vox, voy, psi);
+            m[0] = rm.still ? 0.0 : rm.heading;
+            m[2] = rm.speed;
+            m[4] = rm.course;
+        }
         const double d = fmax(dist[o], 0.0);
         const int inrange = d < range;
         const double fd = 1.0 - (inrange ? d : 0.0) / range;

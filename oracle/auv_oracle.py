@@ -565,7 +565,8 @@ class OracleEnv:
         self.own, self.meta = encounter_metadata(self.state, self.circles, self.poly_pose,
                                                  self.poly_heading, self.obst_dist)
         if int(cfg.get("risk_model", 0)) == 1:
-            from .ref_cri import risk_reference
+            from .ref_cri import reference_metadata, risk_reference
+            self.meta = reference_metadata(self.state, self.circles, self.poly_pose, self.meta)
             self.risk = risk_reference(self.state, self.circles, self.poly_pose, self.obst_dist, R)
         else:
             self.risk = risk_default(self.state, self.circles, self.poly_pose, self.obst_dist,

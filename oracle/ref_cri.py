@@ -113,36 +113,75 @@ def reference_course(own_speed, own_heading, heading_ts, speed_ts):
     return heading_ts + np.arctan2(s * own_speed * np.sin(dl), speed_ts - own_speed * np.cos(dl))
 
 
-def risk_reference(state, circles, poly_pose, dist, sensor_range):
-    """Per-obstacle risk [V, C+P] of a simulator state with the index above.
-
-    The inputs of the index are formed the way the reference forms them: the
-    vessel's velocity is its speed along its heading; an obstacle without a
-    velocity takes the static course (+x when the heading is positive, -x
-    otherwise) and no aspect term; an obstacle with a velocity is headed along
-    it, and the relative course is its velocity minus the vessel's, the latter
-    mirrored about the obstacle's heading when heading_ts - heading_OS leaves
-    (-pi, pi].  p is the hull distance along the direction of the obstacle's
-    centre; 0 outside sensor range."""
-    C = circles.shape[1]
-    P = poly_pose.shape[1]
-    V = state.shape[1]
-    px, py, psi, u, v = state[0], state[1], state[2], state[3], state[4]
+def reference_motion(ovx, ovy, vox, voy, psi):
+    """Relative motion of an obstacle the way the reference forms it; returns
+    (still, hx, hy, heading_ts, rx, ry, speed, course).  The vessel's velocity
+    is its speed along its heading; an obstacle without a velocity is static;
+    one with a velocity is headed along it, and its relative velocity is its
+    own minus the vessel's, the latter mirrored about the obstacle's heading
+    when heading_ts - heading_OS leaves (-pi, pi]."""
     s, c = sincos(psi)
-    vox = c * u - s * v
-    voy = s * u + c * v
     ss = np.sqrt(vox * vox + voy * voy)
     sx = ss * c
     sy = ss * s
-    risk = np.zeros((V, C + P), dtype=np.float64)
-    for o in range(C + P):
-        if o < C:
-            cx, cy = circles[:, o, 0], circles[:, o, 1]
-            ovx, ovy = circles[:, o, 3], circles[:, o, 4]
-        else:
-            k = o - C
-            cx, cy = poly_pose[:, k, 0], poly_pose[:, k, 1]
-            ovx, ovy = poly_pose[:, k, 4], poly_pose[:, k, 5]
+    still = (ovx == 0.0) & (ovy == 0.0)
+    so = np.sqrt(ovx * ovx + ovy * ovy)
+    sos = np.where(still, 1.0, so)
+    hx = ovx / sos
+    hy = ovy / sos
+    heading = atan2(ovy, ovx)
+    mirror = np.abs(heading - psi) > PI
+    dot = sx * hx + sy * hy
+    ex = np.where(mirror, (2.0 * dot) * hx - sx, sx)
+    ey = np.where(mirror, (2.0 * dot) * hy - sy, sy)
+    rx = ovx - ex
+    ry = ovy - ey
+    rn = np.sqrt(rx * rx + ry * ry)
+    speed = np.where(still, ss, rn)
+    course = np.where(still, np.where(psi > 0.0, 0.0, 0.0 - PI), atan2(ry, rx))
+    return still, hx, hy, heading, rx, ry, speed, course
+
+
+def _own_velocity(state):
+    psi, u, v = state[2], state[3], state[4]
+    s, c = sincos(psi)
+    return c * u - s * v, s * u + c * v
+
+
+def _obstacle(circles, poly_pose, o):
+    C = circles.shape[1]
+    if o < C:
+        return circles[:, o, 0], circles[:, o, 1], circles[:, o, 3], circles[:, o, 4]
+    k = o - C
+    return poly_pose[:, k, 0], poly_pose[:, k, 1], poly_pose[:, k, 4], poly_pose[:, k, 5]
+
+
+def reference_metadata(state, circles, poly_pose, meta):
+    """The heading_ts, speed and course columns of `meta` [V, O, 5] in the
+    reference's conventions (dist and bearing are the same in both)."""
+    vox, voy = _own_velocity(state)
+    out = meta.copy()
+    for o in range(circles.shape[1] + poly_pose.shape[1]):
+        _, _, ovx, ovy = _obstacle(circles, poly_pose, o)
+        still, _, _, heading, _, _, speed, course = reference_motion(ovx, ovy, vox, voy, state[2])
+        out[:, o, 0] = np.where(still, 0.0, heading)
+        out[:, o, 2] = speed
+        out[:, o, 4] = course
+    return out
+
+
+def risk_reference(state, circles, poly_pose, dist, sensor_range):
+    """Per-obstacle risk [V, C+P] of a simulator state with the index above;
+    inputs formed as in `reference_motion`.  p is the hull distance along the
+    direction of the obstacle's centre; 0 outside sensor range."""
+    V = state.shape[1]
+    px, py, psi = state[0], state[1], state[2]
+    vox, voy = _own_velocity(state)
+    O = circles.shape[1] + poly_pose.shape[1]
+    risk = np.zeros((V, O), dtype=np.float64)
+    for o in range(O):
+        cx, cy, ovx, ovy = _obstacle(circles, poly_pose, o)
+        still, hx, hy, _, rx, ry, speed, _ = reference_motion(ovx, ovy, vox, voy, psi)
         mx = cx - px
         my = cy - py
         d = dist[:, o]
@@ -151,27 +190,13 @@ def risk_reference(state, circles, poly_pose, dist, sensor_range):
         ns = np.where(has_n, n, 1.0)
         ux = np.where(has_n, mx / ns, 1.0)
         uy = np.where(has_n, my / ns, 0.0)
-        still = (ovx == 0.0) & (ovy == 0.0)
-        so = np.sqrt(ovx * ovx + ovy * ovy)
-        sos = np.where(still, 1.0, so)
-        hx = ovx / sos
-        hy = ovy / sos
-        dl = atan2(ovy, ovx) - psi
-        mirror = np.abs(dl) > PI
-        dot = sx * hx + sy * hy
-        ex = np.where(mirror, (2.0 * dot) * hx - sx, sx)
-        ey = np.where(mirror, (2.0 * dot) * hy - sy, sy)
-        rx = ovx - ex
-        ry = ovy - ey
-        rn = np.sqrt(rx * rx + ry * ry)
-        rns = np.where(rn > 0.0, rn, 1.0)
+        rns = np.where(speed > 0.0, speed, 1.0)
         dvx = np.where(still, np.where(psi > 0.0, 1.0, -1.0), rx / rns)
         dvy = np.where(still, 0.0, ry / rns)
-        moving = np.where(still, ss > 0.0, rn > 0.0)
         ca = 0.0 - (ux * hx + uy * hy)
         aspect = np.where(still, 0.0, ca * np.abs(ca))
         b = wrap_angle(atan2(my, mx) - psi)
         with np.errstate(invalid="ignore"):   # absent slots have d = +inf; they are gated to 0
-            r = cri_core(d * ux, d * uy, dvx, dvy, moving, d, b, aspect)
+            r = cri_core(d * ux, d * uy, dvx, dvy, speed > 0.0, d, b, aspect)
         risk[:, o] = np.where(d < sensor_range, r, 0.0)
     return risk

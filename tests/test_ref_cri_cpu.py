@@ -163,3 +163,30 @@ def test_c_oracle_equals_numpy_oracle_with_the_reference_index():
     assert np.array_equal(env.ranges, default.ranges)          # and nothing else
     assert np.array_equal(env.risk[~np.isfinite(env.obst_dist)], np.zeros((~np.isfinite(env.obst_dist)).sum()))
     cenv.close()
+
+
+def test_rows_written_in_reference_mode_give_back_their_own_risk():
+    """With the reference index selected the metadata columns follow the
+    reference's conventions, so a dataset written from the simulation is
+    self-consistent the way the reference's files are: the record form of the
+    index, applied to the metadata row, returns the logged risk."""
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=400)
+    cfg = dict(cfg, risk_model=1)
+    scene["circles"][1::4, 0, 3:5] = -0.2
+    env = make_oracle(cfg, scene)
+    env.reset(scene["init_state"])
+    acts = scenarios.random_actions(400, 20, seed=8)
+    for k in range(20):
+        env.step(acts[k])
+    O = env.meta.shape[1]
+    own_speed = np.repeat(env.own[:, 0:1], O, axis=1)
+    own_heading = np.repeat(env.own[:, 1:2], O, axis=1)
+    m = env.meta
+    got = ref_cri.cri_rows(own_speed, own_heading, m[:, :, 0], m[:, :, 1], m[:, :, 2], m[:, :, 3], m[:, :, 4])
+    seen = env.obst_dist < cfg["sensor_range"]
+    assert seen.sum() > 1000
+    assert np.abs(got - env.risk)[seen].max() < 1e-9
+    still = (m[:, :, 0] == 0.0) & (m[:, :, 2] == own_speed)
+    assert still[:, 1:8].all() and not still[1::4, 0].any()   # circles at rest are static records, the moving one is not
+    assert set(np.unique(m[:, 1:8, 4])) <= {0.0, -np.pi}      # static obstacles: course 0 / -pi
+    assert not still[:, 8:].any()                              # ships are moving records

@@ -89,3 +89,27 @@ def test_simulation_with_the_reference_index(mode):
     env.step(acts[0])
     assert_all_equal(sim, env, "after switching back")
     sim.close()
+
+
+def test_full_size_rows_give_back_their_own_risk():
+    """65,536 vessels x 16 obstacles in reference mode: the record form of the
+    index (`auv_risk_rows`), fed the metadata the simulation wrote, returns the
+    risk the simulation wrote - the property the reference's own files have."""
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving")
+    cfg = dict(cfg, risk_model=_lib.RISK_REFERENCE)
+    sim = make_sim(cfg, scene)
+    sim.reset(scene["init_state"])
+    acts = scenarios.random_actions(cfg["n_envs"], 6, seed=12)
+    for k in range(6):
+        sim.step_host(acts[k])
+    own, meta, risk, dist = sim.tensor("own"), sim.tensor("meta"), sim.tensor("risk"), sim.tensor("obst_dist")
+    O = meta.shape[1]
+    cols = [own[:, 0:1].expand(-1, O).reshape(-1), own[:, 1:2].expand(-1, O).reshape(-1)]
+    cols += [meta[:, :, f].reshape(-1) for f in range(5)]
+    got = sim.risk_rows(*[c.contiguous() for c in cols]).reshape(risk.shape)
+    torch.cuda.synchronize()
+    seen = dist < cfg["sensor_range"]
+    assert int(seen.sum()) > 100000
+    assert float((got - risk).abs()[seen].max()) < 1e-9
+    assert float(risk[~seen].abs().max()) == 0.0
+    sim.close()
