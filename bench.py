@@ -134,6 +134,8 @@ def main():
                          "restarting them inside the next step, as a vectorised RL env does")
     ap.add_argument("--meta-every", type=int, default=1,
                     help="refresh the per-obstacle bearing/course/risk every n-th step only (default 1: every step)")
+    ap.add_argument("--risk-model", default="default", choices=["default", "reference"],
+                    help="risk index: the default CPA index, or the reference's index recovered from its dataset")
     ap.add_argument("--gather-scans", action="store_true",
                     help="also gather the final scans of every rank on rank 0 once per rollout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,6 +186,8 @@ def main():
         sim.set_option(_lib.OPT_AUTO_RESET, 1)
     if args.meta_every != 1:
         sim.set_option(_lib.OPT_META_EVERY, args.meta_every)
+    if args.risk_model == "reference":
+        sim.set_option(_lib.OPT_RISK_MODEL, _lib.RISK_REFERENCE)
     sim.set_scene(scene)
     stream = torch.cuda.current_stream(dev)
     sim.reset(scene["init_state"], stream=stream)
@@ -312,7 +316,7 @@ def main():
                                if net is not None else
                                f"{args.cnn} (features head) on every step's scans, inside k_sense" if cnn_dim
                                else "none"),
-                       "meta_every": args.meta_every,
+                       "meta_every": args.meta_every, "risk_model": args.risk_model,
                        "auto_reset": "finished episodes restart inside the next step, on the device" if auto_reset
                                      else "off",
                        "sharding": f"envs x{world}, no data-path collective"},

@@ -349,10 +349,10 @@ __global__ __launch_bounds__(256) void k_encounter(EncArgs a) {
         m[3] = wrap_angle(atan2_det(my, mx) - psi);
         if (a.risk_model == 1) {
             // speed, heading and course columns follow the reference's conventions
-            const RefMotion rm = reference_motion(vx, vy, vox, voy, psi);
-            m[0] = rm.still ? 0.0 : rm.heading;
-            m[2] = rm.speed;
-            m[4] = rm.course;
+            const RefMotion rm = reference_motion(vx, vy, vox, voy, sc.c, sc.s, psi);
+            m[0] = rm.still ? 0.0 : atan2_det(vy, vx);
+            m[2] = rm.still ? rm.ss : __builtin_sqrt(rm.rr);
+            m[4] = rm.still ? (psi > 0.0 ? 0.0 : 0.0 - kPi) : atan2_det(rm.wy, rm.wx);
         } else {
             m[0] = hd;
             m[2] = __builtin_sqrt(vv);
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void k_encounter(EncArgs a) {
         const double fc = 1.0 - (dcpa < R ? dcpa : R) / R;
         const double term_c = (a.w_c * (fc * fc)) * (a.t_c / (a.t_c + tcpa));
         const double rr = term_d + (has_c ? term_c : 0.0);
-        a.risk[eo] = a.risk_model == 1 ? risk_reference(mx, my, vx, vy, vox, voy, dist, psi, R) : (inrange ? rr : 0.0);
+        a.risk[eo] = a.risk_model == 1 ? risk_reference(mx, my, vx, vy, vox, voy, dist, sc.c, sc.s, psi, R) : (inrange ? rr : 0.0);
     }
     __syncthreads();
     for (int el = threadIdx.x; el < ne; el += blockDim.x) {

@@ -99,4 +99,18 @@ __device__ __forceinline__ double atan2_det(double y, double x) {
     return zero ? 0.0 : a;
 }
 
+// t / b, correctly rounded, for a divisor whose correctly rounded reciprocal
+// y = RN(1/b) is known (b > 0, t >= 0): t*y refined twice with exact FMA
+// residuals; the second refinement starts from a faithful quotient, which makes
+// its result the rounded true quotient.  Quotients so small that a residual
+// could underflow take the divider.
+__device__ __forceinline__ double div_by_const(double t, double b, double y) {
+    if (__builtin_expect(!(t >= 0x1p-900) && t != 0.0, 0)) return t / b;
+    double q = t * y;
+    double r = __builtin_fma(-q, b, t);
+    q = __builtin_fma(r, y, q);
+    r = __builtin_fma(-q, b, t);
+    return __builtin_fma(r, y, q);
+}
+
 }  // namespace auv

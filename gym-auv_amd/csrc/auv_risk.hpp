@@ -22,21 +22,24 @@ constexpr double kCriD1 = 32.0, kCriD2 = 160.0;      // CPA distances: full risk
 constexpr double kCriDa = 20.08, kCriDb = 45.18;     // range term: full risk / none
 constexpr double kCriWb = 0.2, kCriWct = 0.3, kCriWd = 0.3, kCriWa = 0.2;
 
+// quotients by constants: exact products for the powers of two, the correctly
+// rounded quotient (div_by_const) for the others; bit-equal to a division
+constexpr double kCriSpan = kCriDb - kCriDa;
+
 __device__ __forceinline__ double cri_bearing_membership(double b) {
     const double bd = b * kCriRad2Deg;
-    const double q1 = (90.0 - bd) / 80.0;
-    const double q2 = (bd + 270.0) / 225.0;
+    const double q1 = div_by_const(__builtin_fabs(90.0 - bd), 80.0, 1.0 / 80.0);
+    const double q2 = div_by_const(__builtin_fabs(bd + 270.0), 225.0, 1.0 / 225.0);
     return bd < -45.0 ? q2 * q2 : (bd <= 10.0 ? 1.0 : (bd < 90.0 ? q1 * q1 : 0.0));
 }
 
-__device__ __forceinline__ double cri_core(double px, double py, double vx, double vy, bool moving, double d, double b,
-                                           double aspect) {
-    const double along = px * vx + py * vy;
-    const double cross = px * vy - py * vx;
+// along = p . v, cross = p x v for the obstacle position p and the unit
+// relative-course direction v
+__device__ __forceinline__ double cri_terms(double along, double cross, bool moving, double d, double b, double aspect) {
     const double dc = __builtin_fabs(cross);
     const double ln = __builtin_fabs(along);
     const bool near = dc <= kCriD1;
-    const double lin = (kCriD2 - dc) / (kCriD2 - kCriD1);
+    const double lin = (kCriD2 - dc) * 0.0078125;   // / (D2 - D1)
     const double u_dc = near ? 1.0 : (lin > 0.0 ? lin : 0.0);
     const double r2 = kCriD2 * kCriD2 - dc * dc;
     const double t2 = __builtin_sqrt(r2 > 0.0 ? r2 : 0.0);
@@ -47,12 +50,12 @@ __device__ __forceinline__ double cri_core(double px, double py, double vx, doub
     q = q > 0.0 ? q : 0.0;
     q = q < 1.0 ? q : 1.0;
     const double u_ta = ln <= t1 ? 1.0 : q;
-    const double o = 1.0 - ln / kCriD1;
+    const double o = 1.0 - ln * 0.03125;            // / D1
     const double u_tr = o > 0.0 ? o : 0.0;
     const double u_t = along < 0.0 ? u_ta : u_tr;
     const double ct = moving ? (kCriWct * u_dc) * u_t : 0.0;
-    double qd = (kCriDb - d) / (kCriDb - kCriDa);
-    qd = qd > 0.0 ? qd : 0.0;
+    const double span = kCriDb - d;
+    const double qd = span > 0.0 ? div_by_const(span, kCriSpan, 1.0 / kCriSpan) : 0.0;
     const double u_d = d <= kCriDa ? 1.0 : qd * qd;
     const double total = ((kCriWb * cri_bearing_membership(b) + ct) + kCriWd * u_d) + kCriWa * aspect;
     return total > 0.0 ? total : 0.0;
@@ -60,61 +63,61 @@ __device__ __forceinline__ double cri_core(double px, double py, double vx, doub
 
 // The relative motion of one obstacle the way the reference forms it: the
 // vessel's velocity is its speed along its heading; an obstacle without a
-// velocity is static (course 0 for a positive heading, -pi otherwise, relative
-// speed = the vessel's speed); one with a velocity is headed along it, and its
-// relative velocity is its own minus the vessel's, the latter mirrored about
-// the obstacle's heading when heading_ts - heading_OS leaves (-pi, pi].
+// velocity is static (course along +x for a positive heading, -x otherwise);
+// one with a velocity o is headed along it, and its relative velocity is o
+// minus the vessel's, the latter mirrored about o when heading_ts - heading_OS
+// leaves (-pi, pi].  With X = (cos psi, sin psi) x o that is: psi < 0 < o_y
+// and X < 0, or o_y < 0 < psi and X > 0.
 struct RefMotion {
-    bool still;      // obstacle without a velocity
-    double hx, hy;   // unit heading of a moving obstacle
-    double heading;  // heading_ts: atan2 of its velocity, 0 when still
-    double rx, ry;   // relative velocity (moving obstacle)
-    double speed;    // relative speed
-    double course;   // logged relative course, (-pi, pi]
+    bool still;     // obstacle without a velocity
+    double ss;      // the vessel's speed
+    double wx, wy;  // a vector along the relative course ...
+    double ww;      // ... and its squared length
+    double rr;      // squared relative speed of a moving obstacle
 };
 
-__device__ __forceinline__ RefMotion reference_motion(double ovx, double ovy, double vox, double voy, double psi) {
+__device__ __forceinline__ RefMotion reference_motion(double ovx, double ovy, double vox, double voy, double cpsi,
+                                                      double spsi, double psi) {
     RefMotion m;
-    const SinCos sc = sincos_det(psi);
-    const double ss = __builtin_sqrt(vox * vox + voy * voy);
-    const double sx = ss * sc.c;
-    const double sy = ss * sc.s;
+    m.ss = __builtin_sqrt(vox * vox + voy * voy);
+    const double sx = m.ss * cpsi;
+    const double sy = m.ss * spsi;
     m.still = ovx == 0.0 && ovy == 0.0;
-    const double so = __builtin_sqrt(ovx * ovx + ovy * ovy);
-    const double sos = m.still ? 1.0 : so;
-    m.hx = ovx / sos;
-    m.hy = ovy / sos;
-    m.heading = atan2_det(ovy, ovx);
-    const bool mirror = __builtin_fabs(m.heading - psi) > kPi;
-    const double dot = sx * m.hx + sy * m.hy;
-    const double ex = mirror ? (2.0 * dot) * m.hx - sx : sx;
-    const double ey = mirror ? (2.0 * dot) * m.hy - sy : sy;
-    m.rx = ovx - ex;
-    m.ry = ovy - ey;
-    const double rn = __builtin_sqrt(m.rx * m.rx + m.ry * m.ry);
-    m.speed = m.still ? ss : rn;
-    m.course = m.still ? (psi > 0.0 ? 0.0 : 0.0 - kPi) : atan2_det(m.ry, m.rx);
+    const double oo = ovx * ovx + ovy * ovy;
+    const double X = cpsi * ovy - spsi * ovx;
+    const bool mirror = (spsi < 0.0 && ovy > 0.0 && X < 0.0) || (spsi > 0.0 && ovy < 0.0 && X > 0.0);
+    const double dot = sx * ovx + sy * ovy;
+    const double f = (2.0 * dot) / (m.still ? 1.0 : oo);
+    const double ex = mirror ? f * ovx - sx : sx;
+    const double ey = mirror ? f * ovy - sy : sy;
+    const double rx = ovx - ex;
+    const double ry = ovy - ey;
+    m.rr = rx * rx + ry * ry;
+    m.wx = m.still ? (psi > 0.0 ? 1.0 : -1.0) : rx;
+    m.wy = m.still ? 0.0 : ry;
+    m.ww = m.still ? 1.0 : m.rr;
     return m;
 }
 
 // One obstacle of a simulator state: m = centre relative to the vessel, (ovx,
 // ovy) the obstacle's velocity, (vox, voy) the vessel's, dist the signed hull
-// distance, psi the vessel's heading.
+// distance, psi the vessel's heading with its cosine and sine.  The obstacle
+// position is the hull distance along m, so p . v = dist (m . w)/(|m||w|).
 __device__ __forceinline__ double risk_reference(double mx, double my, double ovx, double ovy, double vox, double voy,
-                                                 double dist, double psi, double range) {
-    const RefMotion rm = reference_motion(ovx, ovy, vox, voy, psi);
-    const double n = __builtin_sqrt(mx * mx + my * my);
-    const bool has_n = n > 0.0;
-    const double ns = has_n ? n : 1.0;
-    const double ux = has_n ? mx / ns : 1.0;
-    const double uy = has_n ? my / ns : 0.0;
-    const double rns = rm.speed > 0.0 ? rm.speed : 1.0;
-    const double dvx = rm.still ? (psi > 0.0 ? 1.0 : -1.0) : rm.rx / rns;
-    const double dvy = rm.still ? 0.0 : rm.ry / rns;
-    const double ca = 0.0 - (ux * rm.hx + uy * rm.hy);
-    const double aspect = rm.still ? 0.0 : ca * __builtin_fabs(ca);
+                                                 double dist, double cpsi, double spsi, double psi, double range) {
+    const RefMotion rm = reference_motion(ovx, ovy, vox, voy, cpsi, spsi, psi);
+    const double mm = mx * mx + my * my;
+    const double den = __builtin_sqrt(mm * rm.ww);
+    const double dens = den > 0.0 ? den : 1.0;
+    const bool moving = rm.still ? rm.ss > 0.0 : rm.rr > 0.0;
+    const double mo = mx * ovx + my * ovy;
+    const double ad = mm * (ovx * ovx + ovy * ovy);
+    const bool has_ad = ad > 0.0;
+    const double aspect = (rm.still || !has_ad) ? 0.0 : 0.0 - (mo * __builtin_fabs(mo)) / (has_ad ? ad : 1.0);
     const double b = wrap_angle(atan2_det(my, mx) - psi);
-    const double r = cri_core(dist * ux, dist * uy, dvx, dvy, rm.speed > 0.0, dist, b, aspect);
+    const double along = dist * ((mx * rm.wx + my * rm.wy) / dens);
+    const double cross = dist * ((mx * rm.wy - my * rm.wx) / dens);
+    const double r = cri_terms(along, cross, moving, dist, b, aspect);
     return dist < range ? r : 0.0;
 }
 
@@ -141,7 +144,8 @@ __global__ __launch_bounds__(256) void k_risk_rows(RiskRowsArgs a) {
     const bool is_static = ht == 0.0 && rs == a.own_speed[i];  // utils/explore_dataset.py:46
     const double ca = sincos_det(bw - ht).c;                   // cos(a) = -cos(a - pi)
     const double aspect = is_static ? 0.0 : 0.0 - ca * __builtin_fabs(ca);
-    a.out[i] = cri_core(d * w.c, d * w.s, c.c, c.s, rs > 0.0, d, b, aspect);
+    const double px = d * w.c, py = d * w.s;
+    a.out[i] = cri_terms(px * c.c + py * c.s, px * c.s - py * c.c, rs > 0.0, d, b, aspect);
 }
 
 }  // namespace auv

@@ -277,20 +277,6 @@ __device__ __forceinline__ PairHit pair_test(unsigned int pr, int R, int n_circ,
     return h;
 }
 
-// t / b, correctly rounded, for a divisor whose correctly rounded reciprocal
-// y = RN(1/b) is known (b > 0, t >= 0): t*y refined twice with exact FMA
-// residuals; the second refinement starts from a faithful quotient, which makes
-// its result the rounded true quotient.  Quotients so small that a residual
-// could underflow take the divider.
-__device__ __forceinline__ double div_by_const(double t, double b, double y) {
-    if (__builtin_expect(!(t >= 0x1p-900) && t != 0.0, 0)) return t / b;
-    double q = t * y;
-    double r = __builtin_fma(-q, b, t);
-    q = __builtin_fma(r, y, q);
-    r = __builtin_fma(-q, b, t);
-    return __builtin_fma(r, y, q);
-}
-
 // default risk index of one obstacle (m = centre relative to the vessel, rv =
 // relative velocity, dist = signed hull distance)
 __device__ __forceinline__ double risk_index(double mx, double my, double rvx, double rvy, double vv, double dist,
@@ -646,12 +632,14 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
                     const double mx = ob[OB_MX * ob_n], my = ob[OB_MY * ob_n], rvx = ob[OB_RVX * ob_n], rvy = ob[OB_RVY * ob_n];
                     const size_t eo = (size_t)e * O + o;
                     double* m = a.meta + eo * 5;
-                    // RISK == 1: speed, heading and course columns follow the reference's conventions
+                    // RISK == 1: the heading, speed and course columns follow the reference's
+                    // conventions and are written with the bearing / course tasks
+                    const double* ov = o < C ? a.circles + ((size_t)e * C + o) * 5 + 3
+                                             : a.poly_pose + ((size_t)e * P + (o - C)) * 6 + 4;
                     auto ref_motion = [&]() -> RefMotion {
-                        const double* ov = o < C ? a.circles + ((size_t)e * C + o) * 5 + 3
-                                                 : a.poly_pose + ((size_t)e * P + (o - C)) * 6 + 4;
                         const double* er = a.envrec + (size_t)e * ER_COUNT;
-                        return reference_motion(ov[0], ov[1], er[ER_VOX], er[ER_VOY], a.state[2 * (size_t)V + e]);
+                        return reference_motion(ov[0], ov[1], er[ER_VOX], er[ER_VOY], er[ER_COS], er[ER_SIN],
+                                                a.state[2 * (size_t)V + e]);
                     };
                     if (task == 0) {
                         dist = hull_distance(ob, el, o);
@@ -668,30 +656,29 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
                         }
                         a.obst_dist[eo] = dist;
                         m[1] = dist;
-                        if (RISK == 1) {
-                            const RefMotion rm = ref_motion();
-                            m[0] = rm.still ? 0.0 : rm.heading;
-                            m[2] = rm.speed;
-                        } else {
+                        if (RISK == 0) {
                             m[0] = hd;
                             m[2] = __builtin_sqrt(rvx * rvx + rvy * rvy);
                         }
                     } else if (task == 3) {
                         if (RISK == 1) {
-                            const double* ov = o < C ? a.circles + ((size_t)e * C + o) * 5 + 3
-                                                     : a.poly_pose + ((size_t)e * P + (o - C)) * 6 + 4;
                             const double* er = a.envrec + (size_t)e * ER_COUNT;
                             a.risk[eo] = risk_reference(mx, my, ov[0], ov[1], er[ER_VOX], er[ER_VOY],
-                                                        hull_distance(ob, el, o), a.state[2 * (size_t)V + e], range);
+                                                        hull_distance(ob, el, o), er[ER_COS], er[ER_SIN],
+                                                        a.state[2 * (size_t)V + e], range);
                         } else {
                             a.risk[eo] = risk_index(mx, my, rvx, rvy, rvx * rvx + rvy * rvy, hull_distance(ob, el, o), range,
                                                     a.inv_range, a.w_d, a.w_c, a.t_c);
                         }
                     } else if (RISK == 1 && task == 2) {
-                        m[4] = ref_motion().course;
+                        const RefMotion rm = ref_motion();
+                        const double psi = a.state[2 * (size_t)V + e];
+                        m[2] = rm.still ? rm.ss : __builtin_sqrt(rm.rr);
+                        m[4] = rm.still ? (psi > 0.0 ? 0.0 : 0.0 - kPi) : atan2_det(rm.wy, rm.wx);
                     } else {
                         const double psi = a.state[2 * (size_t)V + e];
                         m[2 + task] = wrap_angle(atan2_det(task == 1 ? my : rvy, task == 1 ? mx : rvx) - psi);
+                        if (RISK == 1 && task == 1) m[0] = (ov[0] == 0.0 && ov[1] == 0.0) ? 0.0 : atan2_det(ov[1], ov[0]);
                     }
                 }
                 if (task == 0 && lanes_per_env) {

@@ -76,13 +76,11 @@ typedef struct {
 /* oracle/ref_cri.py: bearing_membership, cri_core, risk_reference -- the
  * reference's risk index as recovered from its dataset
  * files (data/metadata_MovingObstaclesNoRules.csv, data/risk_MovingObstaclesNoRules.csv). */
-static double oc_cri_core(double px, double py, double vx, double vy, int moving, double d, double b, double aspect) {
+static double oc_cri_terms(double along, double cross, int moving, double d, double b, double aspect) {
     const double D1 = 32.0, D2 = 160.0, DA = 20.08, DB = 45.18;
-    const double along = px * vx + py * vy;
-    const double cross = px * vy - py * vx;
     const double dc = fabs(cross), ln = fabs(along);
     const int near = dc <= D1;
-    const double lin = (D2 - dc) / (D2 - D1);
+    const double lin = (D2 - dc) * 0.0078125;
     const double u_dc = near ? 1.0 : (lin > 0.0 ? lin : 0.0);
     const double r2 = D2 * D2 - dc * dc;
     const double t2 = sqrt(r2 > 0.0 ? r2 : 0.0);
@@ -93,15 +91,15 @@ static double oc_cri_core(double px, double py, double vx, double vy, int moving
     q = q > 0.0 ? q : 0.0;
     q = q < 1.0 ? q : 1.0;
     const double u_ta = ln <= t1 ? 1.0 : q;
-    const double o = 1.0 - ln / D1;
+    const double o = 1.0 - ln * 0.03125;
     const double u_tr = o > 0.0 ? o : 0.0;
     const double u_t = along < 0.0 ? u_ta : u_tr;
     const double ct = moving ? (0.3 * u_dc) * u_t : 0.0;
-    double qd = (DB - d) / (DB - DA);
-    qd = qd > 0.0 ? qd : 0.0;
+    const double span = DB - d;
+    const double qd = span > 0.0 ? span / (DB - DA) : 0.0;
     const double u_d = d <= DA ? 1.0 : qd * qd;
     const double bd = b * 57.29577951308232;
-    const double q1 = (90.0 - bd) / 80.0, q2 = (bd + 270.0) / 225.0;
+    const double q1 = fabs(90.0 - bd) / 80.0, q2 = fabs(bd + 270.0) / 225.0;
     const double u_b = bd < -45.0 ? q2 * q2 : (bd <= 10.0 ? 1.0 : (bd < 90.0 ? q1 * q1 : 0.0));
     const double total = ((0.2 * u_b + ct) + 0.3 * u_d) + 0.2 * aspect;
     return total > 0.0 ? total : 0.0;
@@ -149,46 +147,44 @@ static double oc_atan2(double y, double x) {
 static double oc_wrap(double a) { return a - floor((a + PI) * INV_TWO_PI) * TWO_PI; }
 
 /* oracle/ref_cri.py: reference_motion */
-typedef struct { int still; double hx, hy, heading, rx, ry, speed, course; } oc_ref_motion;
-static oc_ref_motion oc_reference_motion(double ovx, double ovy, double vox, double voy, double psi) {
+typedef struct { int still; double ss, wx, wy, ww, rr; } oc_ref_motion;
+static oc_ref_motion oc_reference_motion(double ovx, double ovy, double vox, double voy, double cpsi, double spsi,
+                                         double psi) {
     oc_ref_motion m;
-    double sn, cs;
-    oc_sincos(psi, &sn, &cs);
-    const double ss = sqrt(vox * vox + voy * voy);
-    const double sx = ss * cs, sy = ss * sn;
+    m.ss = sqrt(vox * vox + voy * voy);
+    const double sx = m.ss * cpsi, sy = m.ss * spsi;
     m.still = ovx == 0.0 && ovy == 0.0;
-    const double so = sqrt(ovx * ovx + ovy * ovy);
-    const double sos = m.still ? 1.0 : so;
-    m.hx = ovx / sos;
-    m.hy = ovy / sos;
-    m.heading = oc_atan2(ovy, ovx);
-    const int mirror = fabs(m.heading - psi) > PI;
-    const double dot = sx * m.hx + sy * m.hy;
-    const double ex = mirror ? (2.0 * dot) * m.hx - sx : sx;
-    const double ey = mirror ? (2.0 * dot) * m.hy - sy : sy;
-    m.rx = ovx - ex;
-    m.ry = ovy - ey;
-    const double rn = sqrt(m.rx * m.rx + m.ry * m.ry);
-    m.speed = m.still ? ss : rn;
-    m.course = m.still ? (psi > 0.0 ? 0.0 : 0.0 - PI) : oc_atan2(m.ry, m.rx);
+    const double oo = ovx * ovx + ovy * ovy;
+    const double X = cpsi * ovy - spsi * ovx;
+    const int mirror = (spsi < 0.0 && ovy > 0.0 && X < 0.0) || (spsi > 0.0 && ovy < 0.0 && X > 0.0);
+    const double dot = sx * ovx + sy * ovy;
+    const double f = (2.0 * dot) / (m.still ? 1.0 : oo);
+    const double ex = mirror ? f * ovx - sx : sx;
+    const double ey = mirror ? f * ovy - sy : sy;
+    const double rx = ovx - ex, ry = ovy - ey;
+    m.rr = rx * rx + ry * ry;
+    m.wx = m.still ? (psi > 0.0 ? 1.0 : -1.0) : rx;
+    m.wy = m.still ? 0.0 : ry;
+    m.ww = m.still ? 1.0 : m.rr;
     return m;
 }
 
 /* oracle/ref_cri.py: risk_reference */
 static double oc_risk_reference(double mx, double my, double ovx, double ovy, double vox, double voy, double dist,
-                                double psi, double range) {
-    const oc_ref_motion rm = oc_reference_motion(ovx, ovy, vox, voy, psi);
-    const double n = sqrt(mx * mx + my * my);
-    const int has_n = n > 0.0;
-    const double ns = has_n ? n : 1.0;
-    const double ux = has_n ? mx / ns : 1.0, uy = has_n ? my / ns : 0.0;
-    const double rns = rm.speed > 0.0 ? rm.speed : 1.0;
-    const double dvx = rm.still ? (psi > 0.0 ? 1.0 : -1.0) : rm.rx / rns;
-    const double dvy = rm.still ? 0.0 : rm.ry / rns;
-    const double ca = 0.0 - (ux * rm.hx + uy * rm.hy);
-    const double aspect = rm.still ? 0.0 : ca * fabs(ca);
+                                double cpsi, double spsi, double psi, double range) {
+    const oc_ref_motion rm = oc_reference_motion(ovx, ovy, vox, voy, cpsi, spsi, psi);
+    const double mm = mx * mx + my * my;
+    const double den = sqrt(mm * rm.ww);
+    const double dens = den > 0.0 ? den : 1.0;
+    const int moving = rm.still ? rm.ss > 0.0 : rm.rr > 0.0;
+    const double mo = mx * ovx + my * ovy;
+    const double ad = mm * (ovx * ovx + ovy * ovy);
+    const int has_ad = ad > 0.0;
+    const double aspect = (rm.still || !has_ad) ? 0.0 : 0.0 - (mo * fabs(mo)) / (has_ad ? ad : 1.0);
     const double b = oc_wrap(oc_atan2(my, mx) - psi);
-    const double r = oc_cri_core(dist * ux, dist * uy, dvx, dvy, rm.speed > 0.0, dist, b, aspect);
+    const double along = dist * ((mx * rm.wx + my * rm.wy) / dens);
+    const double cross = dist * ((mx * rm.wy - my * rm.wx) / dens);
+    const double r = oc_cri_terms(along, cross, moving, dist, b, aspect);
     return dist < range ? r : 0.0;
 }
 
@@ -378,10 +374,10 @@ static void oc_sense_env(const oc_config *cf, const oc_buffers *b, int e, int is
         m[3] = oc_wrap(oc_atan2(my, mx) - psi);
         m[4] = oc_wrap(oc_atan2(rvy, rvx) - psi);
         if (cf->risk_model == 1) { /* oracle/ref_cri.py: reference_metadata */
-            const oc_ref_motion rm = oc_reference_motion(vx, vy, vox, voy, psi);
-            m[0] = rm.still ? 0.0 : rm.heading;
-            m[2] = rm.speed;
-            m[4] = rm.course;
+            const oc_ref_motion rm = oc_reference_motion(vx, vy, vox, voy, c, s, psi);
+            m[0] = rm.still ? 0.0 : oc_atan2(vy, vx);
+            m[2] = rm.still ? rm.ss : sqrt(rm.rr);
+            m[4] = rm.still ? (psi > 0.0 ? 0.0 : 0.0 - PI) : oc_atan2(rm.wy, rm.wx);
         }
         const double d = fmax(dist[o], 0.0);
         const int inrange = d < range;
@@ -397,7 +393,7 @@ static void oc_sense_env(const oc_config *cf, const oc_buffers *b, int e, int is
         const double term_c = (w_c * (fc * fc)) * (t_c / (t_c + tcpa));
         const double rr = term_d + (has_c ? term_c : 0.0);
         b->risk[(size_t)e * O + o] = cf->risk_model == 1
-            ? oc_risk_reference(mx, my, vx, vy, vox, voy, dist[o], psi, range) : (inrange ? rr : 0.0);
+            ? oc_risk_reference(mx, my, vx, vy, vox, voy, dist[o], c, s, psi, range) : (inrange ? rr : 0.0);
     }
 
     /* navigation, flags, reward */

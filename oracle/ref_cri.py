@@ -57,35 +57,40 @@ CRI_W_A = 0.2
 
 def bearing_membership(b):
     bd = np.asarray(b, dtype=np.float64) * RAD2DEG
-    q1 = (90.0 - bd) / 80.0
-    q2 = (bd + 270.0) / 225.0
+    q1 = np.abs(90.0 - bd) / 80.0
+    q2 = np.abs(bd + 270.0) / 225.0
     return np.where(bd < -45.0, q2 * q2,
                     np.where(bd <= 10.0, 1.0,
                              np.where(bd < 90.0, q1 * q1, 0.0)))
 
 
-def cri_core(px, py, vx, vy, moving, d, b, aspect):
-    """px, py: obstacle position; vx, vy: unit relative-course direction;
-    moving: relative speed > 0; d: surface distance; b: body bearing (rad);
-    aspect: u_A (0 for a static obstacle)."""
-    along = px * vx + py * vy
-    cross = px * vy - py * vx
+def cri_terms(along, cross, moving, d, b, aspect):
+    """along = p . v, cross = p x v for the obstacle position p and the unit
+    relative-course direction v; moving: relative speed > 0; d: surface
+    distance; b: body bearing (rad); aspect: u_A (0 for a static obstacle).
+    Divisions by 128 and 32 are written as the exact products they are."""
     dc = np.abs(cross)
     ln = np.abs(along)
     near = dc <= CRI_D1
-    u_dc = np.where(near, 1.0, np.maximum((CRI_D2 - dc) / (CRI_D2 - CRI_D1), 0.0))
+    u_dc = np.where(near, 1.0, np.maximum((CRI_D2 - dc) * 0.0078125, 0.0))
     t2 = np.sqrt(np.maximum(CRI_D2 * CRI_D2 - dc * dc, 0.0))
     t1 = np.where(near, np.sqrt(np.maximum(CRI_D1 * CRI_D1 - dc * dc, 0.0)), CRI_D1 - dc)
     den = t2 - t1
     q = (t2 - ln) / np.where(den > 0.0, den, 1.0)
     u_ta = np.where(ln <= t1, 1.0, np.minimum(np.maximum(q, 0.0), 1.0))
-    u_tr = np.maximum(1.0 - ln / CRI_D1, 0.0)
+    u_tr = np.maximum(1.0 - ln * 0.03125, 0.0)
     u_t = np.where(along < 0.0, u_ta, u_tr)
     ct = np.where(moving, (CRI_W_CT * u_dc) * u_t, 0.0)
-    qd = np.maximum((CRI_DB - d) / (CRI_DB - CRI_DA), 0.0)
+    span = CRI_DB - d
+    qd = np.where(span > 0.0, span / (CRI_DB - CRI_DA), 0.0)
     u_d = np.where(d <= CRI_DA, 1.0, qd * qd)
     total = ((CRI_W_B * bearing_membership(b) + ct) + CRI_W_D * u_d) + CRI_W_A * aspect
     return np.maximum(total, 0.0)
+
+
+def cri_core(px, py, vx, vy, moving, d, b, aspect):
+    """`cri_terms` for a position p and a unit direction v."""
+    return cri_terms(px * vx + py * vy, px * vy - py * vx, moving, d, b, aspect)
 
 
 def cri_rows(own_speed, own_heading, heading_ts, dist, rel_speed, bearing, course):
@@ -115,31 +120,36 @@ def reference_course(own_speed, own_heading, heading_ts, speed_ts):
 
 def reference_motion(ovx, ovy, vox, voy, psi):
     """Relative motion of an obstacle the way the reference forms it; returns
-    (still, hx, hy, heading_ts, rx, ry, speed, course).  The vessel's velocity
-    is its speed along its heading; an obstacle without a velocity is static;
-    one with a velocity is headed along it, and its relative velocity is its
-    own minus the vessel's, the latter mirrored about the obstacle's heading
-    when heading_ts - heading_OS leaves (-pi, pi]."""
-    s, c = sincos(psi)
+    (still, ss, wx, wy, ww, rr): `still` = obstacle without a velocity, ss the
+    vessel's speed, (wx, wy) a vector along the relative course with squared
+    length ww, rr the squared relative speed of a moving obstacle.
+
+    The vessel's velocity is its speed along its heading; an obstacle without
+    a velocity is static (course along +x for a positive heading, -x
+    otherwise); one with a velocity o is headed along it, and its relative
+    velocity is o minus the vessel's velocity, the latter mirrored about o when
+    heading_ts - heading_OS leaves (-pi, pi].  That condition is evaluated
+    without angles: with X = (cos psi, sin psi) x o, it holds iff psi < 0 < o_y
+    and X < 0, or o_y < 0 < psi and X > 0."""
+    spsi, cpsi = sincos(psi)
     ss = np.sqrt(vox * vox + voy * voy)
-    sx = ss * c
-    sy = ss * s
+    sx = ss * cpsi
+    sy = ss * spsi
     still = (ovx == 0.0) & (ovy == 0.0)
-    so = np.sqrt(ovx * ovx + ovy * ovy)
-    sos = np.where(still, 1.0, so)
-    hx = ovx / sos
-    hy = ovy / sos
-    heading = atan2(ovy, ovx)
-    mirror = np.abs(heading - psi) > PI
-    dot = sx * hx + sy * hy
-    ex = np.where(mirror, (2.0 * dot) * hx - sx, sx)
-    ey = np.where(mirror, (2.0 * dot) * hy - sy, sy)
+    oo = ovx * ovx + ovy * ovy
+    X = cpsi * ovy - spsi * ovx
+    mirror = ((spsi < 0.0) & (ovy > 0.0) & (X < 0.0)) | ((spsi > 0.0) & (ovy < 0.0) & (X > 0.0))
+    dot = sx * ovx + sy * ovy
+    f = (2.0 * dot) / np.where(still, 1.0, oo)
+    ex = np.where(mirror, f * ovx - sx, sx)
+    ey = np.where(mirror, f * ovy - sy, sy)
     rx = ovx - ex
     ry = ovy - ey
-    rn = np.sqrt(rx * rx + ry * ry)
-    speed = np.where(still, ss, rn)
-    course = np.where(still, np.where(psi > 0.0, 0.0, 0.0 - PI), atan2(ry, rx))
-    return still, hx, hy, heading, rx, ry, speed, course
+    rr = rx * rx + ry * ry
+    wx = np.where(still, np.where(psi > 0.0, 1.0, -1.0), rx)
+    wy = np.where(still, 0.0, ry)
+    ww = np.where(still, 1.0, rr)
+    return still, ss, wx, wy, ww, rr
 
 
 def _own_velocity(state):
@@ -158,22 +168,28 @@ def _obstacle(circles, poly_pose, o):
 
 def reference_metadata(state, circles, poly_pose, meta):
     """The heading_ts, speed and course columns of `meta` [V, O, 5] in the
-    reference's conventions (dist and bearing are the same in both)."""
+    reference's conventions (dist and bearing are the same in both):
+    heading_ts = direction of the obstacle's velocity (0 at rest), speed = the
+    relative speed (the vessel's own at rest), course = world-frame direction of
+    the relative velocity (0 / -pi at rest)."""
     vox, voy = _own_velocity(state)
+    psi = state[2]
     out = meta.copy()
     for o in range(circles.shape[1] + poly_pose.shape[1]):
         _, _, ovx, ovy = _obstacle(circles, poly_pose, o)
-        still, _, _, heading, _, _, speed, course = reference_motion(ovx, ovy, vox, voy, state[2])
-        out[:, o, 0] = np.where(still, 0.0, heading)
-        out[:, o, 2] = speed
-        out[:, o, 4] = course
+        still, ss, wx, wy, _, rr = reference_motion(ovx, ovy, vox, voy, psi)
+        out[:, o, 0] = np.where(still, 0.0, atan2(ovy, ovx))
+        out[:, o, 2] = np.where(still, ss, np.sqrt(rr))
+        out[:, o, 4] = np.where(still, np.where(psi > 0.0, 0.0, 0.0 - PI), atan2(wy, wx))
     return out
 
 
 def risk_reference(state, circles, poly_pose, dist, sensor_range):
     """Per-obstacle risk [V, C+P] of a simulator state with the index above;
-    inputs formed as in `reference_motion`.  p is the hull distance along the
-    direction of the obstacle's centre; 0 outside sensor range."""
+    inputs formed as in `reference_motion`.  The obstacle position p is the
+    hull distance along the direction of the obstacle's centre m, so
+    p . v = dist (m . w)/(|m||w|) and likewise p x v; the aspect is
+    -(m . o)|m . o| / (|m|^2 |o|^2).  0 outside sensor range."""
     V = state.shape[1]
     px, py, psi = state[0], state[1], state[2]
     vox, voy = _own_velocity(state)
@@ -181,22 +197,21 @@ def risk_reference(state, circles, poly_pose, dist, sensor_range):
     risk = np.zeros((V, O), dtype=np.float64)
     for o in range(O):
         cx, cy, ovx, ovy = _obstacle(circles, poly_pose, o)
-        still, hx, hy, _, rx, ry, speed, _ = reference_motion(ovx, ovy, vox, voy, psi)
+        still, ss, wx, wy, ww, rr = reference_motion(ovx, ovy, vox, voy, psi)
         mx = cx - px
         my = cy - py
         d = dist[:, o]
-        n = np.sqrt(mx * mx + my * my)
-        has_n = n > 0.0
-        ns = np.where(has_n, n, 1.0)
-        ux = np.where(has_n, mx / ns, 1.0)
-        uy = np.where(has_n, my / ns, 0.0)
-        rns = np.where(speed > 0.0, speed, 1.0)
-        dvx = np.where(still, np.where(psi > 0.0, 1.0, -1.0), rx / rns)
-        dvy = np.where(still, 0.0, ry / rns)
-        ca = 0.0 - (ux * hx + uy * hy)
-        aspect = np.where(still, 0.0, ca * np.abs(ca))
+        mm = mx * mx + my * my
+        den = np.sqrt(mm * ww)
+        dens = np.where(den > 0.0, den, 1.0)
+        moving = np.where(still, ss > 0.0, rr > 0.0)
+        mo = mx * ovx + my * ovy
+        ad = mm * (ovx * ovx + ovy * ovy)
+        aspect = np.where(still | ~(ad > 0.0), 0.0, 0.0 - (mo * np.abs(mo)) / np.where(ad > 0.0, ad, 1.0))
         b = wrap_angle(atan2(my, mx) - psi)
         with np.errstate(invalid="ignore"):   # absent slots have d = +inf; they are gated to 0
-            r = cri_core(d * ux, d * uy, dvx, dvy, speed > 0.0, d, b, aspect)
+            along = d * ((mx * wx + my * wy) / dens)
+            cross = d * ((mx * wy - my * wx) / dens)
+            r = cri_terms(along, cross, moving, d, b, aspect)
         risk[:, o] = np.where(d < sensor_range, r, 0.0)
     return risk

@@ -49,6 +49,31 @@ def test_risk_rows_reproduce_the_reference_dataset():
     sim.close()
 
 
+def test_risk_rows_equal_the_oracle_on_a_million_random_records():
+    """The device takes its quotients by constants as exact products / refined
+    reciprocals; they have to be the divisions the oracle writes, on every input."""
+    cfg, scene = scenarios.make_workload("cfg2_4096_static", n_envs=8)
+    sim = make_sim(cfg, scene)
+    rng = np.random.default_rng(77)
+    n = 1 << 20
+    g = {
+        "own_speed": rng.uniform(0.0, 1.2, n), "own_heading": rng.uniform(-np.pi, np.pi, n),
+        "heading_ts": rng.uniform(-np.pi, np.pi, n), "dist": rng.uniform(-10.0, 200.0, n),
+        "rel_speed": rng.uniform(0.0, 2.0, n), "bearing": rng.uniform(-np.pi, np.pi, n),
+        "course": rng.uniform(-np.pi, np.pi, n),
+    }
+    g["heading_ts"][::3] = 0.0
+    g["rel_speed"][::3] = g["own_speed"][::3]          # static records
+    g["rel_speed"][::7] = 0.0
+    g["dist"][::11] = rng.uniform(19.0, 46.0, len(g["dist"][::11]))   # around the range term's breakpoints
+    g["bearing"][::13] = np.radians(rng.choice([-45.0, 10.0, 90.0, -180.0, 0.0], len(g["bearing"][::13])))
+    got = _rows(sim, g)
+    want = ref_cri.cri_rows(*[g[k] for k in COLS])
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {n} records differ from the oracle"
+    assert want.min() == 0.0 and want.max() > 0.9
+    sim.close()
+
+
 def test_risk_rows_rejects_bad_arguments():
     cfg, scene = scenarios.make_workload("cfg2_4096_static", n_envs=8)
     sim = make_sim(cfg, scene)
