@@ -134,8 +134,9 @@ def main():
                          "restarting them inside the next step, as a vectorised RL env does")
     ap.add_argument("--meta-every", type=int, default=1,
                     help="refresh the per-obstacle bearing/course/risk every n-th step only (default 1: every step)")
-    ap.add_argument("--risk-model", default="default", choices=["default", "reference"],
-                    help="risk index: the default CPA index, or the reference's index recovered from its dataset")
+    ap.add_argument("--risk-model", default="reference", choices=["reference", "cpa"],
+                    help="risk index: the reference's own (recovered from its dataset files; default), or the "
+                         "self-defined closest-point-of-approach index")
     ap.add_argument("--gather-scans", action="store_true",
                     help="also gather the final scans of every rank on rank 0 once per rollout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -175,6 +176,7 @@ def main():
         args.workload = "cfg3_65536_moving" if world == 1 else "cfg4_8x65536_moving"
     cfg, scene = scenarios.make_workload(args.workload, n_envs=args.envs, rank=rank)
     V, R, C, P, NV = cfg["n_envs"], cfg["n_rays"], cfg["n_circles"], cfg["n_polys"], cfg["n_verts"]
+    cfg["risk_model"] = _lib.RISK_REFERENCE if args.risk_model == "reference" else _lib.RISK_CPA
     sim = AuvSim(cfg, device=local_rank)
     sim.set_option(_lib.OPT_LIDAR_MODE, args.lidar_mode)
     if args.tile:
@@ -186,8 +188,6 @@ def main():
         sim.set_option(_lib.OPT_AUTO_RESET, 1)
     if args.meta_every != 1:
         sim.set_option(_lib.OPT_META_EVERY, args.meta_every)
-    if args.risk_model == "reference":
-        sim.set_option(_lib.OPT_RISK_MODEL, _lib.RISK_REFERENCE)
     sim.set_scene(scene)
     stream = torch.cuda.current_stream(dev)
     sim.reset(scene["init_state"], stream=stream)

@@ -38,7 +38,7 @@ BUFFER_NAMES = {
 OPT_LIDAR_MODE, OPT_RASTER_TILE, OPT_SENSE_BLOCK, OPT_AUTO_RESET, OPT_REGENERATE, OPT_META_EVERY = 0, 1, 2, 3, 4, 5
 OPT_RISK_MODEL = 6
 LIDAR_RASTER, LIDAR_ALL_PAIRS = 0, 1
-RISK_DEFAULT, RISK_REFERENCE = 0, 1
+RISK_CPA, RISK_REFERENCE = 0, 1
 
 # CNN consumers
 CNN_SHALLOW, CNN_2DEEP, CNN_DEEP = 0, 1, 2

@@ -243,7 +243,7 @@ struct EncArgs {
     double rw_progress, rw_collision, rw_goal, rw_cte;
     int max_steps;
     int is_step;  // 1: called from a step (reward from progress), 0: after reset
-    int risk_model;  // 0: default index, 1: the reference's index (auv_risk.hpp)
+    int risk_model;  // 0: the closest-point-of-approach index, 1: the reference's index (auv_risk.hpp)
 };
 
 __device__ __forceinline__ double poly_signed_distance(const double* pose, const double* verts, int nv,
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_encounter(EncArgs a) {
             m[2] = __builtin_sqrt(vv);
             m[4] = wrap_angle(atan2_det(rvy, rvx) - psi);
         }
-        // default risk index
+        // closest-point-of-approach index (AUV_RISK_CPA)
         const double R = a.sensor_range;
         const double d = dist < 0.0 ? 0.0 : dist;
         const bool inrange = d < R;

@@ -33,9 +33,11 @@ __device__ __forceinline__ double cri_bearing_membership(double b) {
     return bd < -45.0 ? q2 * q2 : (bd <= 10.0 ? 1.0 : (bd < 90.0 ? q1 * q1 : 0.0));
 }
 
+// The index is the sum of two halves that share no work, clipped at 0:
+// S = 0.3 u_DCPA u_TCPA + 0.3 u_D and T = 0.2 u_B + 0.2 u_A.
 // along = p . v, cross = p x v for the obstacle position p and the unit
-// relative-course direction v
-__device__ __forceinline__ double cri_terms(double along, double cross, bool moving, double d, double b, double aspect) {
+// relative-course direction v.
+__device__ __forceinline__ double cri_cpa_range_half(double along, double cross, bool moving, double d) {
     const double dc = __builtin_fabs(cross);
     const double ln = __builtin_fabs(along);
     const bool near = dc <= kCriD1;
@@ -57,8 +59,20 @@ __device__ __forceinline__ double cri_terms(double along, double cross, bool mov
     const double span = kCriDb - d;
     const double qd = span > 0.0 ? div_by_const(span, kCriSpan, 1.0 / kCriSpan) : 0.0;
     const double u_d = d <= kCriDa ? 1.0 : qd * qd;
-    const double total = ((kCriWb * cri_bearing_membership(b) + ct) + kCriWd * u_d) + kCriWa * aspect;
+    return ct + kCriWd * u_d;
+}
+
+__device__ __forceinline__ double cri_bearing_aspect_half(double b, double aspect) {
+    return kCriWb * cri_bearing_membership(b) + kCriWa * aspect;
+}
+
+__device__ __forceinline__ double cri_sum(double s_half, double t_half) {
+    const double total = s_half + t_half;
     return total > 0.0 ? total : 0.0;
+}
+
+__device__ __forceinline__ double cri_terms(double along, double cross, bool moving, double d, double b, double aspect) {
+    return cri_sum(cri_cpa_range_half(along, cross, moving, d), cri_bearing_aspect_half(b, aspect));
 }
 
 // The relative motion of one obstacle the way the reference forms it: the
@@ -103,22 +117,35 @@ __device__ __forceinline__ RefMotion reference_motion(double ovx, double ovy, do
 // ovy) the obstacle's velocity, (vox, voy) the vessel's, dist the signed hull
 // distance, psi the vessel's heading with its cosine and sine.  The obstacle
 // position is the hull distance along m, so p . v = dist (m . w)/(|m||w|).
-__device__ __forceinline__ double risk_reference(double mx, double my, double ovx, double ovy, double vox, double voy,
-                                                 double dist, double cpsi, double spsi, double psi, double range) {
+// S half; -inf outside sensor range, which makes the clipped sum 0.
+__device__ __forceinline__ double risk_reference_s(double mx, double my, double ovx, double ovy, double vox, double voy,
+                                                   double dist, double cpsi, double spsi, double psi, double range) {
     const RefMotion rm = reference_motion(ovx, ovy, vox, voy, cpsi, spsi, psi);
     const double mm = mx * mx + my * my;
     const double den = __builtin_sqrt(mm * rm.ww);
     const double dens = den > 0.0 ? den : 1.0;
     const bool moving = rm.still ? rm.ss > 0.0 : rm.rr > 0.0;
-    const double mo = mx * ovx + my * ovy;
-    const double ad = mm * (ovx * ovx + ovy * ovy);
-    const bool has_ad = ad > 0.0;
-    const double aspect = (rm.still || !has_ad) ? 0.0 : 0.0 - (mo * __builtin_fabs(mo)) / (has_ad ? ad : 1.0);
-    const double b = wrap_angle(atan2_det(my, mx) - psi);
     const double along = dist * ((mx * rm.wx + my * rm.wy) / dens);
     const double cross = dist * ((mx * rm.wy - my * rm.wx) / dens);
-    const double r = cri_terms(along, cross, moving, dist, b, aspect);
-    return dist < range ? r : 0.0;
+    const double s_half = cri_cpa_range_half(along, cross, moving, dist);
+    return dist < range ? s_half : 0.0 - __builtin_inf();
+}
+
+// T half from the body bearing b = wrap(atan2(m) - psi); the aspect is
+// -(m . o)|m . o| / (|m|^2 |o|^2) for an obstacle with a velocity.
+__device__ __forceinline__ double risk_reference_t(double mx, double my, double ovx, double ovy, double b) {
+    const double mo = mx * ovx + my * ovy;
+    const double ad = (mx * mx + my * my) * (ovx * ovx + ovy * ovy);
+    const bool has_ad = ad > 0.0;
+    const double aspect = has_ad ? 0.0 - (mo * __builtin_fabs(mo)) / ad : 0.0;
+    return cri_bearing_aspect_half(b, aspect);
+}
+
+__device__ __forceinline__ double risk_reference(double mx, double my, double ovx, double ovy, double vox, double voy,
+                                                 double dist, double cpsi, double spsi, double psi, double range) {
+    const double b = wrap_angle(atan2_det(my, mx) - psi);
+    return cri_sum(risk_reference_s(mx, my, ovx, ovy, vox, voy, dist, cpsi, spsi, psi, range),
+                   risk_reference_t(mx, my, ovx, ovy, b));
 }
 
 // Dataset records -> risk: one thread per obstacle record of a metadata row.

@@ -346,7 +346,7 @@ constexpr int kKeep = 4;  // pair-list passes whose hit keys stay in registers b
 
 // RISK: 0 = default risk index, 1 = the reference's index (auv_risk.hpp)
 template <int RISK>
-__global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k_sense(SenseArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int V = a.d.V, R = a.d.R, C = a.d.C, P = a.d.P, NV = a.d.NV, O = a.d.O;
     const int S = P * NV;
@@ -662,10 +662,18 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
                         }
                     } else if (task == 3) {
                         if (RISK == 1) {
+                            // S half of the index; with the pair list in LDS the T half comes from
+                            // the bearing wave and the two meet after the barrier (the relative-
+                            // velocity fields of the staged record are not read in this mode)
                             const double* er = a.envrec + (size_t)e * ER_COUNT;
-                            a.risk[eo] = risk_reference(mx, my, ov[0], ov[1], er[ER_VOX], er[ER_VOY],
-                                                        hull_distance(ob, el, o), er[ER_COS], er[ER_SIN],
-                                                        a.state[2 * (size_t)V + e], range);
+                            const double psi = a.state[2 * (size_t)V + e];
+                            const double sh = risk_reference_s(mx, my, ov[0], ov[1], er[ER_VOX], er[ER_VOY],
+                                                               hull_distance(ob, el, o), er[ER_COS], er[ER_SIN], psi, range);
+                            if (fits)
+                                ob[OB_RVY * ob_n] = sh;
+                            else
+                                a.risk[eo] = cri_sum(sh, risk_reference_t(mx, my, ov[0], ov[1],
+                                                                          wrap_angle(atan2_det(my, mx) - psi)));
                         } else {
                             a.risk[eo] = risk_index(mx, my, rvx, rvy, rvx * rvx + rvy * rvy, hull_distance(ob, el, o), range,
                                                     a.inv_range, a.w_d, a.w_c, a.t_c);
@@ -677,8 +685,12 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
                         m[4] = rm.still ? (psi > 0.0 ? 0.0 : 0.0 - kPi) : atan2_det(rm.wy, rm.wx);
                     } else {
                         const double psi = a.state[2 * (size_t)V + e];
-                        m[2 + task] = wrap_angle(atan2_det(task == 1 ? my : rvy, task == 1 ? mx : rvx) - psi);
-                        if (RISK == 1 && task == 1) m[0] = (ov[0] == 0.0 && ov[1] == 0.0) ? 0.0 : atan2_det(ov[1], ov[0]);
+                        const double ang = wrap_angle(atan2_det(task == 1 ? my : rvy, task == 1 ? mx : rvx) - psi);
+                        m[2 + task] = ang;
+                        if (RISK == 1 && task == 1) {
+                            if (fits) ob[OB_RVX * ob_n] = risk_reference_t(mx, my, ov[0], ov[1], ang);
+                            m[0] = (ov[0] == 0.0 && ov[1] == 0.0) ? 0.0 : atan2_det(ov[1], ov[0]);
+                        }
                     }
                 }
                 if (task == 0 && lanes_per_env) {
@@ -744,6 +756,11 @@ __global__ __launch_bounds__(512) void k_sense(SenseArgs a) {
         AUV_STAMP(5);
         __syncthreads();
         AUV_STAMP(6);
+        if (RISK == 1 && a.with_meta) {
+            // the two halves of the risk index, left by the bearing and the risk wave
+            for (int i = tid; i < ne * O; i += nthr)
+                a.risk[(size_t)e0 * O + i] = cri_sum(obst[OB_RVY * ob_n + i], obst[OB_RVX * ob_n + i]);
+        }
 #pragma unroll
         for (int j = 0; j < kKeep; ++j)
             if (kept[j].ok && best[kept[j].slot] == kept[j].key) atomicMin(&ids[kept[j].slot], kept[j].oid);

@@ -77,7 +77,7 @@ struct auv_sim {
     int auto_reset = 0;   // done envs restart inside the next step
     int regenerate = 0;   // ... with a newly generated scene
     int meta_every = 1;   // steps between refreshes of bearing / course / risk (0: only outside steps)
-    int risk_model = AUV_RISK_DEFAULT;
+    int risk_model = AUV_RISK_REFERENCE;
     long long step_count = 0;
     bool have_generator = false, have_init = false;
     uint64_t gen_seed = 0;
@@ -901,8 +901,8 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
             h->step_count = 0;
             return AUV_OK;
         case AUV_OPT_RISK_MODEL:
-            if (value != AUV_RISK_DEFAULT && value != AUV_RISK_REFERENCE)
-                return fail(h, AUV_ERR_ARG, "auv_set_option: AUV_OPT_RISK_MODEL takes AUV_RISK_DEFAULT or AUV_RISK_REFERENCE");
+            if (value != AUV_RISK_CPA && value != AUV_RISK_REFERENCE)
+                return fail(h, AUV_ERR_ARG, "auv_set_option: AUV_OPT_RISK_MODEL takes AUV_RISK_REFERENCE or AUV_RISK_CPA");
             h->risk_model = value;
             return AUV_OK;
         case AUV_OPT_REGENERATE:

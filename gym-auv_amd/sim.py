@@ -75,8 +75,7 @@ class AuvSim:
         self.O = self.C + self.P
         _live.add(self)
         self.set_rays(ray_table(self.R) if ray_dirs is None else ray_dirs)
-        if int(cfg.get("risk_model", _lib.RISK_DEFAULT)) != _lib.RISK_DEFAULT:
-            self.set_option(_lib.OPT_RISK_MODEL, int(cfg["risk_model"]))
+        self.set_option(_lib.OPT_RISK_MODEL, int(cfg.get("risk_model", _lib.RISK_REFERENCE)))
 
     # -- lifetime ---------------------------------------------------------
     def close(self):

@@ -66,7 +66,7 @@ typedef struct auv_config {
     double moment_max;
     double look_ahead;
     double goal_radius;
-    double risk[3];         /* w_d, w_c, T_c of the default risk index */
+    double risk[3];         /* w_d, w_c, T_c of the AUV_RISK_CPA index */
     double reward[4];       /* w_progress, w_collision, w_goal, w_cross_track */
     double model[AUV_N_MODEL];
 } auv_config;
@@ -124,21 +124,24 @@ typedef enum auv_option {
                                * read them.  0: never during steps.  Default 1: every step.  Distances,
                                * collision, reward and the observations are always current.  Rasterising
                                * path only (the all-pairs path always refreshes). */
-    AUV_OPT_RISK_MODEL = 6    /* which index fills AUV_BUF_RISK.  AUV_RISK_DEFAULT: the closest-point-of-approach
-                               * index weighted by auv_config.risk.  AUV_RISK_REFERENCE: the reference's own
+    AUV_OPT_RISK_MODEL = 6    /* which index fills AUV_BUF_RISK.  AUV_RISK_REFERENCE (default): the reference's own
                                * index as recovered from data/metadata_MovingObstaclesNoRules.csv against
-                               * data/risk_MovingObstaclesNoRules.csv (0.2 bearing + 0.3 DCPA x TCPA + 0.3 range
+                               * data/risk_MovingObstaclesNoRules.csv (0.3 DCPA x TCPA + 0.3 range + 0.2 bearing
                                * + 0.2 target-aspect memberships, clipped at 0, in the reference's frames); it
                                * reproduces all 23,680 per-obstacle records of those files to 2e-15.  With it
                                * the heading_ts, speed and course fields of AUV_BUF_META follow the reference's
                                * conventions too (heading_ts = direction of the obstacle's velocity, 0 at rest;
                                * course = world-frame direction of the relative velocity as the reference forms
-                               * it, 0 / -pi for an obstacle at rest), so that auv_risk_rows of a metadata row
-                               * gives back the AUV_BUF_RISK row, as in the reference's files. */
+                               * it, 0 / -pi for an obstacle at rest; refreshed with bearing and risk, see
+                               * AUV_OPT_META_EVERY), so that auv_risk_rows of a metadata row gives back the
+                               * AUV_BUF_RISK row, as in the reference's files.  AUV_RISK_CPA: a plain
+                               * closest-point-of-approach index weighted by auv_config.risk, with heading_ts =
+                               * the uploaded polygon heading, speed = |v_obst - v_own|, course relative to
+                               * the vessel's heading. */
 } auv_option;
 #define AUV_LIDAR_RASTER 0
 #define AUV_LIDAR_ALL_PAIRS 1
-#define AUV_RISK_DEFAULT 0
+#define AUV_RISK_CPA 0
 #define AUV_RISK_REFERENCE 1
 
 /* Library build information: "libauvsim <abi> gfx950 ...". */

@@ -53,7 +53,7 @@ enum { MP_MINV11, MP_MINV22, MP_MINV23, MP_MINV32, MP_MINV33, MP_M11, MP_M22, MP
 
 typedef struct {
     int32_t V, R, C, P, NV, max_steps;
-    int32_t risk_model, pad_;   /* 0: default index, 1: oc_risk_reference */
+    int32_t risk_model, pad_;   /* 0: closest-point-of-approach index, 1: oc_risk_reference */
     double dt, sensor_range, vessel_radius, thrust_max, moment_max, look_ahead, goal_radius;
     double risk[3], reward[4], model[16];
 } oc_config;
@@ -101,7 +101,7 @@ static double oc_cri_terms(double along, double cross, int moving, double d, dou
     const double bd = b * 57.29577951308232;
     const double q1 = fabs(90.0 - bd) / 80.0, q2 = fabs(bd + 270.0) / 225.0;
     const double u_b = bd < -45.0 ? q2 * q2 : (bd <= 10.0 ? 1.0 : (bd < 90.0 ? q1 * q1 : 0.0));
-    const double total = ((0.2 * u_b + ct) + 0.3 * u_d) + 0.2 * aspect;
+    const double total = (ct + 0.3 * u_d) + (0.2 * u_b + 0.2 * aspect);
     return total > 0.0 ? total : 0.0;
 }
 
@@ -180,7 +180,7 @@ static double oc_risk_reference(double mx, double my, double ovx, double ovy, do
     const double mo = mx * ovx + my * ovy;
     const double ad = mm * (ovx * ovx + ovy * ovy);
     const int has_ad = ad > 0.0;
-    const double aspect = (rm.still || !has_ad) ? 0.0 : 0.0 - (mo * fabs(mo)) / (has_ad ? ad : 1.0);
+    const double aspect = has_ad ? 0.0 - (mo * fabs(mo)) / ad : 0.0;
     const double b = oc_wrap(oc_atan2(my, mx) - psi);
     const double along = dist * ((mx * rm.wx + my * rm.wy) / dens);
     const double cross = dist * ((mx * rm.wy - my * rm.wx) / dens);

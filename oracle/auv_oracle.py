@@ -564,7 +564,7 @@ class OracleEnv:
                                             cfg["vessel_radius"])
         self.own, self.meta = encounter_metadata(self.state, self.circles, self.poly_pose,
                                                  self.poly_heading, self.obst_dist)
-        if int(cfg.get("risk_model", 0)) == 1:
+        if int(cfg.get("risk_model", 1)) == 1:
             from .ref_cri import reference_metadata, risk_reference
             self.meta = reference_metadata(self.state, self.circles, self.poly_pose, self.meta)
             self.risk = risk_reference(self.state, self.circles, self.poly_pose, self.obst_dist, R)

@@ -63,7 +63,7 @@ class COracleEnv:
         O = Cn + P
         c = OcConfig()
         c.V, c.R, c.C, c.P, c.NV, c.max_steps = V, R, Cn, P, NV, cfg["max_steps"]
-        c.risk_model = int(cfg.get("risk_model", 0))
+        c.risk_model = int(cfg.get("risk_model", 1))
         for k in ("dt", "sensor_range", "vessel_radius", "thrust_max", "moment_max", "look_ahead", "goal_radius"):
             setattr(c, k, float(cfg[k]))
         c.risk[:] = [float(x) for x in cfg["risk"]]

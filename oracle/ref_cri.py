@@ -84,7 +84,7 @@ def cri_terms(along, cross, moving, d, b, aspect):
     span = CRI_DB - d
     qd = np.where(span > 0.0, span / (CRI_DB - CRI_DA), 0.0)
     u_d = np.where(d <= CRI_DA, 1.0, qd * qd)
-    total = ((CRI_W_B * bearing_membership(b) + ct) + CRI_W_D * u_d) + CRI_W_A * aspect
+    total = (ct + CRI_W_D * u_d) + (CRI_W_B * bearing_membership(b) + CRI_W_A * aspect)
     return np.maximum(total, 0.0)
 
 
@@ -207,7 +207,7 @@ def risk_reference(state, circles, poly_pose, dist, sensor_range):
         moving = np.where(still, ss > 0.0, rr > 0.0)
         mo = mx * ovx + my * ovy
         ad = mm * (ovx * ovx + ovy * ovy)
-        aspect = np.where(still | ~(ad > 0.0), 0.0, 0.0 - (mo * np.abs(mo)) / np.where(ad > 0.0, ad, 1.0))
+        aspect = np.where(ad > 0.0, 0.0 - (mo * np.abs(mo)) / np.where(ad > 0.0, ad, 1.0), 0.0)
         b = wrap_angle(atan2(my, mx) - psi)
         with np.errstate(invalid="ignore"):   # absent slots have d = +inf; they are gated to 0
             along = d * ((mx * wx + my * wy) / dens)

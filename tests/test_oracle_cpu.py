@@ -215,3 +215,15 @@ def test_oracles_reproduce_the_committed_regression_vectors():
         for name, attr in PAIRS.items():
             want = g[f"final_{name}"]
             assert same_bits(np.asarray(getattr(e, attr)).reshape(want.shape), want), name
+    # the same rollout with the closest-point-of-approach index
+    cfg0 = dict(cfg, risk_model=0)
+    env = make_oracle(cfg0, scene)
+    cenv = c_oracle.COracleEnv(cfg0, params.ray_table(cfg["n_rays"]))
+    cenv.set_scene(scene["circles"], scene["poly_pose"], scene["poly_verts"], scene["poly_nv"], scene["poly_heading"])
+    cenv.set_path(scene["path"])
+    for e in (env, cenv):
+        e.reset(scene["init_state"])
+        for k in range(g["actions"].shape[0]):
+            e.step(g["actions"][k])
+        assert same_bits(np.asarray(e.risk).reshape(g["final_cpa_risk"].shape), g["final_cpa_risk"])
+        assert same_bits(np.asarray(e.meta).reshape(g["final_cpa_meta"].shape), g["final_cpa_meta"])

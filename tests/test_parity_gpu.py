@@ -179,13 +179,18 @@ def test_generated_scenes_and_regeneration_match_oracle():
     sim.close()
 
 
-def test_metadata_refresh_interval():
-    """AUV_OPT_META_EVERY = 5: bearing, course and risk follow the oracle on every
-    fifth step and keep their values in between; everything else (state, scan,
-    distances, flags, reward, the other metadata fields) is current on every step."""
+@pytest.mark.parametrize("risk_model", [1, 0], ids=["reference", "cpa"])
+def test_metadata_refresh_interval(risk_model):
+    """AUV_OPT_META_EVERY = 5: bearing, course and risk (and, with the reference's
+    index, the heading and speed columns that follow its conventions) follow the
+    oracle on every fifth step and keep their values in between; everything else
+    (state, scan, distances, flags, reward, the other metadata fields) is current
+    on every step."""
     from gym_auv_amd import _lib
 
     cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=203)
+    cfg = dict(cfg, risk_model=risk_model)
+    held_fields = [0, 2, 3, 4] if risk_model == 1 else [3, 4]
     sim = make_sim(cfg, scene)
     env = make_oracle(cfg, scene)
     sim.set_option(_lib.OPT_META_EVERY, 5)
@@ -200,7 +205,7 @@ def test_metadata_refresh_interval():
         if (k + 1) % 5 == 0:
             held_meta, held_risk = env.meta.copy(), env.risk.copy()
         want_meta = env.meta.copy()
-        want_meta[..., 3:] = held_meta[..., 3:]
+        want_meta[..., held_fields] = held_meta[..., held_fields]
         assert same_bits(sim.read("meta"), want_meta), k
         assert same_bits(sim.read("risk"), held_risk), k
         for name in ("state", "ranges", "hit", "perception", "navigation", "obst_dist", "collision", "done",
@@ -495,6 +500,13 @@ def test_device_reproduces_the_committed_regression_vectors(mode):
     for name in PAIRS:
         want = g[f"final_{name}"]
         assert same_bits(sim.read(name), want.reshape(sim.read(name).shape)), name
+    sim.close()
+    # the same rollout with the closest-point-of-approach risk index
+    sim = make_sim(dict(cfg, risk_model=0), scene, lidar_mode=mode)
+    sim.reset(scene["init_state"])
+    for k in range(g["actions"].shape[0]):
+        sim.step_host(g["actions"][k])
+    assert same_bits(sim.read("risk"), g["final_cpa_risk"]) and same_bits(sim.read("meta"), g["final_cpa_meta"])
     sim.close()
 
 

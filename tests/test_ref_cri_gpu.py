@@ -107,8 +107,8 @@ def test_simulation_with_the_reference_index(mode):
             assert_all_equal(sim, env, f"after step {k + 1}")
     risk = sim.read("risk")
     assert risk.max() > 0.2 and risk.max() <= 1.0 and risk.min() >= 0.0
-    # back to the default index on the same handle
-    sim.set_option(_lib.OPT_RISK_MODEL, _lib.RISK_DEFAULT)
+    # over to the closest-point-of-approach index on the same handle
+    sim.set_option(_lib.OPT_RISK_MODEL, _lib.RISK_CPA)
     env.cfg = dict(env.cfg, risk_model=0)
     sim.step_host(acts[0])
     env.step(acts[0])
