@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="threads of the CPU baseline (0 = the CPUs this process may use, at most 16)")
     ap.add_argument("--cpu-envs", type=int, default=32768)
-    ap.add_argument("--cpu-steps", type=int, default=40)
+    ap.add_argument("--cpu-steps", type=int, default=200)
     args = ap.parse_args()
 
     import torch
@@ -332,6 +332,8 @@ def main():
                                    "traffic": None, "avg_launch_ms": cnn_ms}
         tkey = f"{args.workload}/{V}/" + (f"{args.cnn}-attached" if cnn_dim else
                                            f"{args.cnn}-separate" if net is not None else "none")
+        if args.risk_model != "reference":
+            tkey += "/" + args.risk_model     # the committed counters are those of the default index
         if fused:
             nbytes = float(sense_bytes_per_env(R, C, P, NV) + 4 * cnn_dim) * V
             gbs = nbytes / sense_s / 1e9
