@@ -198,6 +198,7 @@ def main():
     done_t, coll_t, rew_t = sim.tensor("done"), sim.tensor("collision"), sim.tensor("reward")
     goal_t, trunc_t = sim.tensor("reached_goal"), sim.tensor("truncated")
     per_all = sim.tensor("perception")
+    ranges_t, risk_t = sim.tensor("ranges"), sim.tensor("risk")
 
     # the consumer of the scans: the reference's shipped weights (fixture made from its own files)
     net = feats = per_t = None
@@ -230,7 +231,7 @@ def main():
         # episode statistics of a rollout: one small all-reduce (RCCL), not per step;
         # optionally the last scans of every rank gathered on the trainer rank 0
         st = auv_dist.EpisodeStats(dev)
-        st.update(done_t, coll_t, goal_t, trunc_t, rew_t)
+        st.update(done_t, coll_t, goal_t, trunc_t, rew_t, ranges=ranges_t, risk=risk_t)
         totals = st.reduce()
         if args.gather_scans and per_all is not None:
             auv_dist.gather_scans(per_all, dst=0)
