@@ -33,7 +33,7 @@ __device__ __forceinline__ double cri_bearing_membership(double b) {
     return bd < -45.0 ? q2 * q2 : (bd <= 10.0 ? 1.0 : (bd < 90.0 ? q1 * q1 : 0.0));
 }
 
-// The index is the sum of two halves that share no work, clipped at 0:
+// The index is summed as two halves, clipped at 0:
 // S = 0.3 u_DCPA u_TCPA + 0.3 u_D and T = 0.2 u_B + 0.2 u_A.
 // along = p . v, cross = p x v for the obstacle position p and the unit
 // relative-course direction v.

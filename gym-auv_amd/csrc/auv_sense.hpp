@@ -662,18 +662,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
                         }
                     } else if (task == 3) {
                         if (RISK == 1) {
-                            // S half of the index; with the pair list in LDS the T half comes from
-                            // the bearing wave and the two meet after the barrier (the relative-
-                            // velocity fields of the staged record are not read in this mode)
                             const double* er = a.envrec + (size_t)e * ER_COUNT;
-                            const double psi = a.state[2 * (size_t)V + e];
-                            const double sh = risk_reference_s(mx, my, ov[0], ov[1], er[ER_VOX], er[ER_VOY],
-                                                               hull_distance(ob, el, o), er[ER_COS], er[ER_SIN], psi, range);
-                            if (fits)
-                                ob[OB_RVY * ob_n] = sh;
-                            else
-                                a.risk[eo] = cri_sum(sh, risk_reference_t(mx, my, ov[0], ov[1],
-                                                                          wrap_angle(atan2_det(my, mx) - psi)));
+                            a.risk[eo] = risk_reference(mx, my, ov[0], ov[1], er[ER_VOX], er[ER_VOY],
+                                                        hull_distance(ob, el, o), er[ER_COS], er[ER_SIN],
+                                                        a.state[2 * (size_t)V + e], range);
                         } else {
                             a.risk[eo] = risk_index(mx, my, rvx, rvy, rvx * rvx + rvy * rvy, hull_distance(ob, el, o), range,
                                                     a.inv_range, a.w_d, a.w_c, a.t_c);
@@ -687,10 +679,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
                         const double psi = a.state[2 * (size_t)V + e];
                         const double ang = wrap_angle(atan2_det(task == 1 ? my : rvy, task == 1 ? mx : rvx) - psi);
                         m[2 + task] = ang;
-                        if (RISK == 1 && task == 1) {
-                            if (fits) ob[OB_RVX * ob_n] = risk_reference_t(mx, my, ov[0], ov[1], ang);
-                            m[0] = (ov[0] == 0.0 && ov[1] == 0.0) ? 0.0 : atan2_det(ov[1], ov[0]);
-                        }
+                        if (RISK == 1 && task == 1) m[0] = (ov[0] == 0.0 && ov[1] == 0.0) ? 0.0 : atan2_det(ov[1], ov[0]);
                     }
                 }
                 if (task == 0 && lanes_per_env) {
@@ -756,11 +745,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
         AUV_STAMP(5);
         __syncthreads();
         AUV_STAMP(6);
-        if (RISK == 1 && a.with_meta) {
-            // the two halves of the risk index, left by the bearing and the risk wave
-            for (int i = tid; i < ne * O; i += nthr)
-                a.risk[(size_t)e0 * O + i] = cri_sum(obst[OB_RVY * ob_n + i], obst[OB_RVX * ob_n + i]);
-        }
 #pragma unroll
         for (int j = 0; j < kKeep; ++j)
             if (kept[j].ok && best[kept[j].slot] == kept[j].key) atomicMin(&ids[kept[j].slot], kept[j].oid);
