@@ -46,7 +46,7 @@ def main():
     x[2, 0, 170:] = 0.9                          # obstacle across the wrap-around
     x[2, 0, :10] = 0.9
     x[3, 0, :] = np.linspace(0, 1, 180, dtype=np.float32)
-    # the survey's check vector: torch.manual_seed(0); torch.rand(4,1,180)
+    # seeded check vector: torch.manual_seed(0); torch.rand(4,1,180)
     torch.manual_seed(0)
     x[4:8] = torch.rand(4, 1, 180).numpy()
     xt = torch.from_numpy(x)
@@ -72,7 +72,7 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     np.savez_compressed(os.path.join(here, "cnn_golden.npz"), **out)
     print({k: v.shape for k, v in out.items()})
-    print("survey check:", out["shallow_risk"][4:8, 0], out["deep2_risk"][4:8, 0], out["deep_risk"][4:8, 0])
+    print("seeded check:", out["shallow_risk"][4:8, 0], out["deep2_risk"][4:8, 0], out["deep_risk"][4:8, 0])
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@ def test_oracle_reproduces_reference_outputs(gold, tag, head):
     assert np.abs(y - ref).max() <= TOL
 
 
-def test_survey_known_answers(gold):
+def test_known_answers_of_the_shipped_models(gold):
     # torch.manual_seed(0); x = torch.rand(4,1,180) through the three shipped models
     assert np.allclose(gold["shallow_risk"][4:8, 0], [0.91553873, 1.11435294, 1.03119719, 1.01221919], atol=1e-6)
     assert np.allclose(gold["deep2_risk"][4:8, 0], [1.03762591, 1.09775817, 1.11773407, 1.12432921], atol=1e-6)
