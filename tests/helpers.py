@@ -52,3 +52,32 @@ def assert_all_equal(sim, env, where=""):
             nbad = int((got != w).sum())
             bad.append(f"{name}: {nbad}/{got.size} differ")
     assert not bad, f"device != oracle {where}: " + "; ".join(bad)
+
+
+def risk_edge_case_scene(V=64):
+    """(cfg, scene) that walks the corner cases of the reference's risk index:
+    headings of exactly 0 and -pi, vessels at rest and under way, an obstacle
+    centred on the vessel, obstacles sailing exactly along the axes, ships
+    without a velocity, obstacle headings on both sides of every heading so
+    that the mirrored-course branch and its boundary signs are hit."""
+    from gym_auv_amd import scenarios
+
+    cfg = params.make_config(V, 4, 4, 5)
+    scene = scenarios.make_scene(V, 4, 4, 5, seed=31, extent=120.0)
+    init = scene["init_state"]
+    init[2, 0::8] = 0.0                      # heading exactly 0
+    init[2, 1::8] = -np.pi                   # the other end of [-pi, pi)
+    init[2, 2::8] = np.pi / 2
+    init[3, 0::2] = 0.7                      # every other vessel under way from the first step
+    init[4, 3::4] = 0.05                     # some sway
+    c, p = scene["circles"], scene["poly_pose"]
+    c[0::4, 0, 0:2] = init[0:2, 0::4].T      # circle centred on the vessel
+    c[1::4, 1, 3:5] = (0.4, 0.0)             # circles sailing along +x / -x / +y / -y
+    c[2::4, 1, 3:5] = (-0.4, 0.0)
+    c[1::4, 2, 3:5] = (0.0, 0.3)
+    c[2::4, 2, 3:5] = (0.0, -0.3)
+    p[0::3, 0, 4:6] = 0.0                    # a ship without a velocity
+    p[1::3, 1, 4:6] = (-0.5, 1e-300)         # heading a hair under pi
+    p[2::3, 1, 4:6] = (-0.5, -1e-300)        # and a hair over -pi
+    scene["path"][:, 2] = init[2]
+    return cfg, scene

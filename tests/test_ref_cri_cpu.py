@@ -11,7 +11,7 @@ import numpy as np
 
 from gym_auv_amd import params, scenarios
 from oracle import c_oracle, ref_cri
-from tests.helpers import PAIRS, make_oracle, same_bits
+from tests.helpers import PAIRS, make_oracle, risk_edge_case_scene, same_bits
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "cri_golden.npz")
 TOL = 2e-15   # the reference's own operation order is unknown; all records agree to 1.1e-15
@@ -190,3 +190,20 @@ def test_rows_written_in_reference_mode_give_back_their_own_risk():
     assert still[:, 1:8].all() and not still[1::4, 0].any()   # circles at rest are static records, the moving one is not
     assert set(np.unique(m[:, 1:8, 4])) <= {0.0, -np.pi}      # static obstacles: course 0 / -pi
     assert not still[:, 8:].any()                              # ships are moving records
+
+
+def test_c_oracle_equals_numpy_oracle_on_the_corner_cases_of_the_index():
+    cfg, scene = risk_edge_case_scene()
+    env, cenv = _pair(cfg, scene)
+    env.reset(scene["init_state"])
+    cenv.reset(scene["init_state"])
+    acts = scenarios.random_actions(cfg["n_envs"], 8, seed=2)
+    acts[:, :, 1::2] = 0.0                    # half of the vessels never touch the controls
+    for k in range(8):
+        bad = [n for n, a in PAIRS.items() if a != "episode" and not same_bits(
+            np.asarray(getattr(cenv, a)).reshape(np.shape(getattr(env, a))), getattr(env, a))]
+        assert not bad, f"C oracle != numpy oracle before step {k + 1}: {bad}"
+        assert np.isfinite(env.risk).all() and env.risk.min() >= 0.0 and env.risk.max() <= 1.0
+        env.step(acts[k])
+        cenv.step(acts[k])
+    cenv.close()

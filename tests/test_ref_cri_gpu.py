@@ -14,7 +14,7 @@ import torch
 
 from gym_auv_amd import _lib, scenarios
 from oracle import ref_cri
-from tests.helpers import assert_all_equal, make_oracle, make_sim
+from tests.helpers import assert_all_equal, make_oracle, make_sim, risk_edge_case_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -137,4 +137,24 @@ def test_full_size_rows_give_back_their_own_risk():
     assert int(seen.sum()) > 100000
     assert float((got - risk).abs()[seen].max()) < 1e-9
     assert float(risk[~seen].abs().max()) == 0.0
+    sim.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["raster", "allpairs"])
+def test_corner_cases_of_the_index(mode):
+    """Headings of exactly 0 and -pi, vessels at rest, an obstacle centred on
+    the vessel, obstacles sailing along the axes, ships without a velocity,
+    obstacle headings a hair either side of +-pi."""
+    cfg, scene = risk_edge_case_scene()
+    sim = make_sim(cfg, scene, lidar_mode=mode)
+    env = make_oracle(cfg, scene)
+    sim.reset(scene["init_state"])
+    env.reset(scene["init_state"])
+    acts = scenarios.random_actions(cfg["n_envs"], 8, seed=2)
+    acts[:, :, 1::2] = 0.0
+    for k in range(8):
+        assert_all_equal(sim, env, f"before step {k + 1}")
+        sim.step_host(acts[k])
+        env.step(acts[k])
+    assert_all_equal(sim, env, "at the end")
     sim.close()
