@@ -158,6 +158,23 @@ def test_dataset_logger_writes_the_oracles_rows(tmp_path):
     assert data["train"][0].shape == (n_train, 1, 180) and data["test"][1].shape == (n_test, 1)
     # a page-locked read returns the same bytes as a plain one
     assert np.array_equal(sim.read("ranges", pinned=True), sim.read("ranges"))
+    # the files have the relation the reference's own files have: the reference's risk index
+    # applied to a metadata row (read back from the text) gives the risk row
+    from oracle import ref_cri
+
+    meta_rows, risk_rows = D.read_ragged(wd.paths["metadata"]), D.read_ragged(wd.paths["risk"])
+    assert len(meta_rows) == len(risk_rows) == rows
+    n_static = n_moving = 0
+    for m, r in zip(meta_rows, risk_rows):
+        speed_os, heading_os, rec = D.parse_metadata_row(m)
+        assert len(rec) == len(r) >= 1
+        got = ref_cri.cri_rows(np.full(len(rec), speed_os), np.full(len(rec), heading_os), rec[:, 0], rec[:, 1],
+                               rec[:, 2], rec[:, 3], rec[:, 4])
+        assert np.abs(got - r).max() < 1e-9
+        st = np.array([D.is_static(x, speed_os) for x in rec])
+        n_static += int(st.sum())
+        n_moving += int((~st).sum())
+    assert n_static > 100 and n_moving > 100
     sim.close()
 
 
