@@ -37,7 +37,7 @@ def model_constants() -> np.ndarray:
     return np.array([
         1.0 / m11, m33 / det, -m23 / det, -m32 / det, m22 / det,
         m11, m22, m23,
-        2.0, 1.32742, 7.0, 36.47287, 0.1, 0.1, 0.5, 0.75,
+        2.0, 0.0, 7.0, 0.0, 0.1, 0.1, 0.5, 0.0,
     ], dtype=np.float64)
 
 
