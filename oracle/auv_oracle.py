@@ -7,8 +7,10 @@ and observation assembly.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` may import it; the product path never
 does.
 
-PARITY UNPINNED for dynamics, obstacle advance, LiDAR, collision and the
-default risk index: the reference checkout (hebe2602/gym-auv @ v1) does not
+PARITY UNPINNED for the sway-yaw block of the dynamics, obstacle advance, LiDAR,
+collision and the closest-point-of-approach risk index (the straight-line
+dynamics -- integrator, step, surge damping, thrust limit -- are pinned by
+samples of the reference's logs, tests/test_ref_surge_cpu.py): the reference checkout (hebe2602/gym-auv @ v1) does not
 contain the simulator (`radarCNN.py:232` only names the absent ``gym_auv/``
 package), so there is no reference function, golden vector or fixture to pin
 these against.  (The reference's own risk index, `ref_cri.py`, IS pinned: by
