@@ -25,7 +25,7 @@ namespace auv {
 
 enum ModelIdx {
     MP_MINV11 = 0, MP_MINV22, MP_MINV23, MP_MINV32, MP_MINV33,
-    MP_M11, MP_M22, MP_M23,
+    MP_MU, MP_MXG, MP_RESERVED,
     MP_XU, MP_XUU, MP_YV, MP_YVV, MP_YR, MP_NV, MP_NR, MP_NRR,
     MP_COUNT
 };
@@ -59,17 +59,15 @@ __device__ __forceinline__ Vec6 vessel_rhs(const Vec6& s, double fx, double mz, 
     o.x = sc.c * s.u - sc.s * s.v;
     o.y = sc.s * s.u + sc.c * s.v;
     o.psi = s.r;
-    const double c13 = -(mp[MP_M22] * s.v + mp[MP_M23] * s.r);
-    const double c23 = mp[MP_M11] * s.u;
-    const double cor1 = c13 * s.r;
-    const double cor2 = c23 * s.r;
-    const double cor3 = -(c13 * s.u) - c23 * s.v;
-    const double d1 = (mp[MP_XU] + mp[MP_XUU] * __builtin_fabs(s.u)) * s.u;
-    const double d2 = (mp[MP_YV] + mp[MP_YVV] * __builtin_fabs(s.v)) * s.v + mp[MP_YR] * s.r;
-    const double d3 = mp[MP_NV] * s.v + (mp[MP_NR] + mp[MP_NRR] * __builtin_fabs(s.r)) * s.r;
-    const double r1 = (fx - cor1) - d1;
-    const double r2 = (0.0 - cor2) - d2;
-    const double r3 = (mz - cor3) - d3;
+    // Linearised manoeuvring model: the velocity-dependent matrix N(nu) holds the
+    // linear damping plus the rigid-body terms m*u (sway) and m*x_g*u (yaw) that
+    // multiply the yaw rate; there is no v*r term in surge.
+    const double n1 = (mp[MP_XU] + mp[MP_XUU] * __builtin_fabs(s.u)) * s.u;
+    const double n2 = (mp[MP_YV] + mp[MP_YVV] * __builtin_fabs(s.v)) * s.v + (mp[MP_MU] * s.u + mp[MP_YR]) * s.r;
+    const double n3 = mp[MP_NV] * s.v + ((mp[MP_MXG] * s.u + mp[MP_NR]) + mp[MP_NRR] * __builtin_fabs(s.r)) * s.r;
+    const double r1 = fx - n1;
+    const double r2 = 0.0 - n2;
+    const double r3 = mz - n3;
     o.u = mp[MP_MINV11] * r1;
     o.v = mp[MP_MINV22] * r2 + mp[MP_MINV23] * r3;
     o.r = mp[MP_MINV32] * r2 + mp[MP_MINV33] * r3;

@@ -3,8 +3,10 @@ device library.
 
 The vessel is a CyberShip-II-like 3-DOF surface craft.  The reference
 checkout does not contain its ship model (only `radarCNN.py:232` names the
-absent ``gym_auv`` package), so these numbers are this project's own choice;
-what the mounted files fix is the sensor suite: 180 rays
+absent ``gym_auv`` package); the model numbers below are the ones that
+reproduce the speed and heading columns of its logged dataset
+(tests/golden/make_surge_golden.py, make_turn_golden.py).  The mounted files
+fix the sensor suite directly: 180 rays
 (`utils/dataloader.py:13`) of 150 m range (`utils/dataloader.py:56,127`).
 """
 from __future__ import annotations
@@ -26,8 +28,14 @@ _XUD, _YVD, _YRD, _NVD, _NRD = -2.0, -10.0, 0.0, 0.0, -1.0
 
 def model_constants() -> np.ndarray:
     """The 16 model numbers in the order the kernels index them:
-    Minv11, Minv22, Minv23, Minv32, Minv33, M11, M22, M23,
-    Xu, Xuu, Yv, Yvv, Yr, Nv, Nr, Nrr (damping given as positive numbers)."""
+    Minv11, Minv22, Minv23, Minv32, Minv33, m, m*x_g, 0 (reserved),
+    Xu, Xuu, Yv, Yvv, Yr, Nv, Nr, Nrr (damping given as positive numbers).
+
+    nu' = Minv (tau - N(nu) nu) with N(nu) nu = [Xu u, Yv v + (m u + Yr) r,
+    Nv v + (m x_g u + Nr) r]: the linearised manoeuvring model (no v*r term in
+    surge, rigid-body mass in the sway coupling).  These numbers reproduce the
+    reference's logged speed and heading through its unactuated turns to
+    1e-15 (tests/golden/make_turn_golden.py)."""
     m11 = _M - _XUD
     m22 = _M - _YVD
     m23 = _M * _XG - _YRD
@@ -36,7 +44,7 @@ def model_constants() -> np.ndarray:
     det = m22 * m33 - m23 * m32
     return np.array([
         1.0 / m11, m33 / det, -m23 / det, -m32 / det, m22 / det,
-        m11, m22, m23,
+        _M, _M * _XG, 0.0,
         2.0, 0.0, 7.0, 0.0, 0.1, 0.1, 0.5, 0.0,
     ], dtype=np.float64)
 

@@ -48,7 +48,7 @@ static const double RK_A[6][5] = {
 };
 static const double RK_B5[6] = {16.0 / 135.0, 0.0, 6656.0 / 12825.0, 28561.0 / 56430.0, -9.0 / 50.0, 2.0 / 55.0};
 
-enum { MP_MINV11, MP_MINV22, MP_MINV23, MP_MINV32, MP_MINV33, MP_M11, MP_M22, MP_M23,
+enum { MP_MINV11, MP_MINV22, MP_MINV23, MP_MINV32, MP_MINV33, MP_MU, MP_MXG, MP_RESERVED,
        MP_XU, MP_XUU, MP_YV, MP_YVV, MP_YR, MP_NV, MP_NR, MP_NRR };
 
 typedef struct {
@@ -193,13 +193,10 @@ static void oc_rhs(const double y[6], double fx, double mz, const double *mp, do
     const double psi = y[2], u = y[3], v = y[4], r = y[5];
     double s, c;
     oc_sincos(psi, &s, &c);
-    const double c13 = -(mp[MP_M22] * v + mp[MP_M23] * r);
-    const double c23 = mp[MP_M11] * u;
-    const double cor1 = c13 * r, cor2 = c23 * r, cor3 = -(c13 * u) - c23 * v;
-    const double d1 = (mp[MP_XU] + mp[MP_XUU] * fabs(u)) * u;
-    const double d2 = (mp[MP_YV] + mp[MP_YVV] * fabs(v)) * v + mp[MP_YR] * r;
-    const double d3 = mp[MP_NV] * v + (mp[MP_NR] + mp[MP_NRR] * fabs(r)) * r;
-    const double r1 = (fx - cor1) - d1, r2 = (0.0 - cor2) - d2, r3 = (mz - cor3) - d3;
+    const double n1 = (mp[MP_XU] + mp[MP_XUU] * fabs(u)) * u;
+    const double n2 = (mp[MP_YV] + mp[MP_YVV] * fabs(v)) * v + (mp[MP_MU] * u + mp[MP_YR]) * r;
+    const double n3 = mp[MP_NV] * v + ((mp[MP_MXG] * u + mp[MP_NR]) + mp[MP_NRR] * fabs(r)) * r;
+    const double r1 = fx - n1, r2 = 0.0 - n2, r3 = mz - n3;
     out[0] = c * u - s * v;
     out[1] = s * u + c * v;
     out[2] = r;

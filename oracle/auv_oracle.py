@@ -83,7 +83,7 @@ RK_B5 = (16.0 / 135.0, 0.0, 6656.0 / 12825.0, 28561.0 / 56430.0, -9.0 / 50.0, 2.
 # indices into the model-constant vector `mp` (length 16); values are supplied
 # by the caller so that oracle and device use identical numbers.
 (MP_MINV11, MP_MINV22, MP_MINV23, MP_MINV32, MP_MINV33,
- MP_M11, MP_M22, MP_M23,
+ MP_MU, MP_MXG, MP_RESERVED,
  MP_XU, MP_XUU, MP_YV, MP_YVV, MP_YR, MP_NV, MP_NR, MP_NRR) = range(16)
 
 NAV_FEATURES = 6
@@ -156,17 +156,12 @@ def vessel_rhs(y, fx, mz, mp):
     s, c = sincos(psi)
     xd = c * u - s * v
     yd = s * u + c * v
-    c13 = -(mp[MP_M22] * v + mp[MP_M23] * r)
-    c23 = mp[MP_M11] * u
-    cor1 = c13 * r
-    cor2 = c23 * r
-    cor3 = -(c13 * u) - c23 * v
-    d1 = (mp[MP_XU] + mp[MP_XUU] * np.abs(u)) * u
-    d2 = (mp[MP_YV] + mp[MP_YVV] * np.abs(v)) * v + mp[MP_YR] * r
-    d3 = mp[MP_NV] * v + (mp[MP_NR] + mp[MP_NRR] * np.abs(r)) * r
-    r1 = (fx - cor1) - d1
-    r2 = (0.0 - cor2) - d2
-    r3 = (mz - cor3) - d3
+    n1 = (mp[MP_XU] + mp[MP_XUU] * np.abs(u)) * u
+    n2 = (mp[MP_YV] + mp[MP_YVV] * np.abs(v)) * v + (mp[MP_MU] * u + mp[MP_YR]) * r
+    n3 = mp[MP_NV] * v + ((mp[MP_MXG] * u + mp[MP_NR]) + mp[MP_NRR] * np.abs(r)) * r
+    r1 = fx - n1
+    r2 = 0.0 - n2
+    r3 = mz - n3
     ud = mp[MP_MINV11] * r1
     vd = mp[MP_MINV22] * r2 + mp[MP_MINV23] * r3
     rd = mp[MP_MINV32] * r2 + mp[MP_MINV33] * r3

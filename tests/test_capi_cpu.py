@@ -78,6 +78,7 @@ def test_dlpack_record_layout():
 
 def test_model_constants_invert_the_mass_matrix():
     mp = params.model_constants()
-    M = np.array([[mp[5], 0, 0], [0, mp[6], mp[7]], [0, mp[7], 2.76]])
+    M = np.array([[25.8, 0, 0], [0, 33.8, mp[6]], [0, mp[6], 2.76]])     # m - X_udot, m - Y_vdot, m x_g, I_z - N_rdot
+    assert mp[5] == 23.8 and mp[6] == 23.8 * 0.046 and mp[7] == 0.0
     Minv = np.array([[mp[0], 0, 0], [0, mp[1], mp[2]], [0, mp[3], mp[4]]])
     assert np.allclose(M @ Minv, np.eye(3), atol=1e-14)

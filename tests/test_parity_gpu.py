@@ -110,7 +110,7 @@ def test_in_step_restart_matches_oracle():
     V = 131
     cfg = params.make_config(V, 6, 6, 5, max_steps=30, goal_radius=5.0)
     scene = scenarios.make_scene(V, 6, 6, 5, seed=25, extent=60.0, width=(8.0, 25.0))
-    scene["path"][:, 5] = 12.0
+    scene["path"][:, 5] = np.array([12.0, 25.0, 60.0])[np.arange(V) % 3]     # short paths end at the goal, long ones run out of steps
     sim = make_sim(cfg, scene)
     sim.set_option(_lib.OPT_AUTO_RESET, 1)
     env = make_oracle(cfg, scene)
