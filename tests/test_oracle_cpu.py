@@ -96,7 +96,7 @@ def test_lidar_known_answers_polygon_and_ties():
     sq = [(40.0, -10.0), (60.0, -10.0), (60.0, 10.0), (40.0, 10.0)]
     env = _one_env(polys=[sq])
     assert abs(env.ranges[0, 89] - 40.0) < 1e-12 and env.hit[0, 89] == 0
-    assert abs(env.obst_dist[0, 0] - (40.0 - 2.0)) < 1e-12
+    assert abs(env.obst_dist[0, 0] - (40.0 - 3.255)) < 1e-12
     # identical circle listed twice: the lower id wins the tie
     env = _one_env(circles=[(50.0, 0.0, 10.0), (50.0, 0.0, 10.0)])
     assert set(np.unique(env.hit[0])) == {-1, 0}
@@ -109,7 +109,7 @@ def test_lidar_known_answers_polygon_and_ties():
 def test_polygon_inside_is_negative_distance():
     sq = [(-10.0, -10.0), (10.0, -10.0), (10.0, 10.0), (-10.0, 10.0)]
     env = _one_env(polys=[sq])
-    assert abs(env.obst_dist[0, 0] - (-10.0 - 2.0)) < 1e-12
+    assert abs(env.obst_dist[0, 0] - (-10.0 - 3.255)) < 1e-12
     assert env.collision[0] == 1
 
 

@@ -143,7 +143,7 @@ def test_generated_scenes_and_regeneration_match_oracle():
     from gym_auv_amd import _lib
 
     V = 133
-    cfg = params.make_config(V, 5, 6, 6, max_steps=25, goal_radius=5.0)
+    cfg = params.make_config(V, 5, 6, 6, max_steps=20, goal_radius=5.0)
     gp = dict(extent=70.0, w_lo=8.0, w_hi=25.0, path_length=14.0, clearance=4.0)
     sim = AuvSim(cfg)
     env = O.OracleEnv(cfg, params.ray_table(cfg["n_rays"]))
@@ -156,8 +156,7 @@ def test_generated_scenes_and_regeneration_match_oracle():
     sim.set_option(_lib.OPT_REGENERATE, 1)
     env.auto_reset = env.regenerate = True
     acts = scenarios.random_actions(V, 100, seed=26)
-    acts[:, 0] = 1.0
-    acts[:, 1] *= 0.1
+    acts[:, 0] = 1.0          # full thrust, free rudder: some vessels reach the goal in 20 steps, some do not
     seen = np.zeros(3, dtype=bool)
     for k in range(100):
         sim.step_host(acts[k])
