@@ -288,6 +288,17 @@ __device__ __forceinline__ double poly_signed_distance(const double* pose, const
     return inside ? -dmin : dmin;
 }
 
+// Beam of a ship: max - min of the body-frame y of its nv >= 1 vertices.
+__device__ __forceinline__ double body_beam(const double* verts, int nv) {
+    double hi = -__builtin_inf(), lo = __builtin_inf();
+    for (int k = 0; k < nv; ++k) {
+        const double y = verts[2 * k + 1];
+        hi = y > hi ? y : hi;
+        lo = y < lo ? y : lo;
+    }
+    return hi - lo;
+}
+
 __global__ __launch_bounds__(256) void k_encounter(EncArgs a) {
     extern __shared__ double lds_dist[];  // [EB*O]
     const int V = a.d.V, C = a.d.C, P = a.d.P, NV = a.d.NV, O = a.d.O;
@@ -306,6 +317,7 @@ __global__ __launch_bounds__(256) void k_encounter(EncArgs a) {
         const double vox = sc.c * u - sc.s * v;
         const double voy = sc.s * u + sc.c * v;
         double cx, cy, vx, vy, hd, dist;
+        double beam = -1.0;  // ships only: extent of the body-frame vertices across the heading
         if (o < C) {
             const double* c = a.circles + ((size_t)e * C + o) * 5;
             cx = c[0];
@@ -330,6 +342,7 @@ __global__ __launch_bounds__(256) void k_encounter(EncArgs a) {
             if (nv > 0) {
                 const double* verts = a.poly_verts + ((size_t)e * P + q) * NV * 2;
                 dist = poly_signed_distance(p, verts, nv, px, py) - a.vessel_radius;
+                beam = body_beam(verts, nv);
             } else {
                 dist = __builtin_inf();
             }
@@ -343,7 +356,10 @@ __global__ __launch_bounds__(256) void k_encounter(EncArgs a) {
         a.obst_dist[eo] = dist;
         lds_dist[i] = dist;
         double* m = a.meta + eo * 5;
-        m[1] = dist;
+        // the reference logs centre distance less size less clearance, for ships too
+        const double dref = (a.risk_model == 1 && beam >= 0.0)
+                                ? (__builtin_sqrt(mx * mx + my * my) - beam) - a.vessel_radius : dist;
+        m[1] = dref;
         m[3] = wrap_angle(atan2_det(my, mx) - psi);
         if (a.risk_model == 1) {
             // speed, heading and course columns follow the reference's conventions
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(256) void k_encounter(EncArgs a) {
         const double fc = 1.0 - (dcpa < R ? dcpa : R) / R;
         const double term_c = (a.w_c * (fc * fc)) * (a.t_c / (a.t_c + tcpa));
         const double rr = term_d + (has_c ? term_c : 0.0);
-        a.risk[eo] = a.risk_model == 1 ? risk_reference(mx, my, vx, vy, vox, voy, dist, sc.c, sc.s, psi, R) : (inrange ? rr : 0.0);
+        a.risk[eo] = a.risk_model == 1 ? risk_reference(mx, my, vx, vy, vox, voy, dref, sc.c, sc.s, psi, R) : (inrange ? rr : 0.0);
     }
     __syncthreads();
     for (int el = threadIdx.x; el < ne; el += blockDim.x) {

@@ -615,6 +615,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
             const double dmin = __builtin_sqrt(dmin2);
             return nv > 0 ? (par ? -dmin : dmin) - a.vessel_radius : __builtin_inf();
         };
+        // the dist column and risk input of the reference's index: centre distance
+        // less size less clearance; a ship's size is its beam (body-frame vertices
+        // across its heading), a circle's its radius, i.e. the hull distance
+        auto ref_distance = [&](const double* ob, int el, int o, int e, double mx, double my) -> double {
+            if (o < C) return ob[OB_DIST * ob_n];
+            const int nv = ecross[el * S + (o - C) * NV] >> 1;
+            const double* vb = a.poly_verts + ((size_t)e * P + (o - C)) * NV * 2;
+            return nv > 0 ? (__builtin_sqrt(mx * mx + my * my) - body_beam(vb, nv)) - a.vessel_radius : __builtin_inf();
+        };
         // when an env's obstacles sit in an aligned power-of-two group of lanes
         // of one wave, its nearest obstacle is a shuffle reduction
         const bool lanes_per_env = O > 0 && (O & (O - 1)) == 0 && TE * O <= 64;
@@ -655,7 +664,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
                             hd = pb[PB_HEADING * pb_n];
                         }
                         a.obst_dist[eo] = dist;
-                        m[1] = dist;
+                        m[1] = RISK == 1 ? ref_distance(ob, el, o, e, mx, my) : dist;
                         if (RISK == 0) {
                             m[0] = hd;
                             m[2] = __builtin_sqrt(rvx * rvx + rvy * rvy);
@@ -664,7 +673,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
                         if (RISK == 1) {
                             const double* er = a.envrec + (size_t)e * ER_COUNT;
                             a.risk[eo] = risk_reference(mx, my, ov[0], ov[1], er[ER_VOX], er[ER_VOY],
-                                                        hull_distance(ob, el, o), er[ER_COS], er[ER_SIN],
+                                                        ref_distance(ob, el, o, e, mx, my), er[ER_COS], er[ER_SIN],
                                                         a.state[2 * (size_t)V + e], range);
                         } else {
                             a.risk[eo] = risk_index(mx, my, rvx, rvy, rvx * rvx + rvy * rvy, hull_distance(ob, el, o), range,

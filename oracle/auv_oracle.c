@@ -370,7 +370,18 @@ static void oc_sense_env(const oc_config *cf, const oc_buffers *b, int e, int is
         m[2] = sqrt(rvx * rvx + rvy * rvy);
         m[3] = oc_wrap(oc_atan2(my, mx) - psi);
         m[4] = oc_wrap(oc_atan2(rvy, rvx) - psi);
-        if (cf->risk_model == 1) { /* oracle/ref_cri.py: reference_metadata */
+        double dref = dist[o];
+        if (cf->risk_model == 1) { /* oracle/ref_cri.py: reference_distances, reference_metadata */
+            if (o >= C && nvs[o - C] > 0) {
+                double hi = -INFINITY, lo = INFINITY;
+                for (int k = 0; k < nvs[o - C]; ++k) {
+                    const double y = verts[((size_t)(o - C) * NV + k) * 2 + 1];
+                    if (y > hi) hi = y;
+                    if (y < lo) lo = y;
+                }
+                dref = (sqrt(mx * mx + my * my) - (hi - lo)) - cf->vessel_radius;
+            }
+            m[1] = dref;
             const oc_ref_motion rm = oc_reference_motion(vx, vy, vox, voy, c, s, psi);
             m[0] = rm.still ? 0.0 : oc_atan2(vy, vx);
             m[2] = rm.still ? rm.ss : sqrt(rm.rr);
@@ -390,7 +401,7 @@ static void oc_sense_env(const oc_config *cf, const oc_buffers *b, int e, int is
         const double term_c = (w_c * (fc * fc)) * (t_c / (t_c + tcpa));
         const double rr = term_d + (has_c ? term_c : 0.0);
         b->risk[(size_t)e * O + o] = cf->risk_model == 1
-            ? oc_risk_reference(mx, my, vx, vy, vox, voy, dist[o], c, s, psi, range) : (inrange ? rr : 0.0);
+            ? oc_risk_reference(mx, my, vx, vy, vox, voy, dref, c, s, psi, range) : (inrange ? rr : 0.0);
     }
 
     /* navigation, flags, reward */

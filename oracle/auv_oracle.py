@@ -562,9 +562,12 @@ class OracleEnv:
         self.own, self.meta = encounter_metadata(self.state, self.circles, self.poly_pose,
                                                  self.poly_heading, self.obst_dist)
         if int(cfg.get("risk_model", 1)) == 1:
-            from .ref_cri import reference_metadata, risk_reference
+            from .ref_cri import reference_distances, reference_metadata, risk_reference
+            dref = reference_distances(self.state, self.circles, self.poly_pose, self.poly_verts, self.poly_nv,
+                                       self.obst_dist, cfg["vessel_radius"])
             self.meta = reference_metadata(self.state, self.circles, self.poly_pose, self.meta)
-            self.risk = risk_reference(self.state, self.circles, self.poly_pose, self.obst_dist, R)
+            self.meta[:, :, 1] = dref
+            self.risk = risk_reference(self.state, self.circles, self.poly_pose, dref, R)
         else:
             self.risk = risk_default(self.state, self.circles, self.poly_pose, self.obst_dist,
                                      R, cfg["risk"])

@@ -166,9 +166,39 @@ def _obstacle(circles, poly_pose, o):
     return poly_pose[:, k, 0], poly_pose[:, k, 1], poly_pose[:, k, 4], poly_pose[:, k, 5]
 
 
+def reference_distances(state, circles, poly_pose, poly_verts, poly_nv, dist, clearance):
+    """The `dist` column the way the reference logs it: centre distance minus
+    the obstacle's size minus a clearance (3.255 m), for ships as for circles.
+    A circle's size is its radius, so its column is the hull distance `dist`
+    already holds; a ship's size is its beam, the extent of its body-frame
+    vertices across its heading (the reference's ship of width w spans
+    -w/2 .. w/2 there).  Pinned by tests/golden/track_golden.npz and
+    ship_golden.npz.  Absent slots keep +inf."""
+    out = np.array(dist, dtype=np.float64, copy=True)
+    C = circles.shape[1]
+    NV = poly_verts.shape[2]
+    px, py = state[0], state[1]
+    for q in range(poly_pose.shape[1]):
+        nv = poly_nv[:, q]
+        hi = np.full(nv.shape, -np.inf)
+        lo = np.full(nv.shape, np.inf)
+        for k in range(NV):
+            y = poly_verts[:, q, k, 1]
+            act = k < nv
+            hi = np.where(act & (y > hi), y, hi)
+            lo = np.where(act & (y < lo), y, lo)
+        mx = poly_pose[:, q, 0] - px
+        my = poly_pose[:, q, 1] - py
+        with np.errstate(invalid="ignore"):
+            d = (np.sqrt(mx * mx + my * my) - (hi - lo)) - clearance
+        out[:, C + q] = np.where(nv > 0, d, np.inf)
+    return out
+
+
 def reference_metadata(state, circles, poly_pose, meta):
     """The heading_ts, speed and course columns of `meta` [V, O, 5] in the
-    reference's conventions (dist and bearing are the same in both):
+    reference's conventions (the bearing is the same in both; the dist column is
+    `reference_distances`, set by the caller):
     heading_ts = direction of the obstacle's velocity (0 at rest), speed = the
     relative speed (the vessel's own at rest), course = world-frame direction of
     the relative velocity (0 / -pi at rest)."""
@@ -186,8 +216,8 @@ def reference_metadata(state, circles, poly_pose, meta):
 
 def risk_reference(state, circles, poly_pose, dist, sensor_range):
     """Per-obstacle risk [V, C+P] of a simulator state with the index above;
-    inputs formed as in `reference_motion`.  The obstacle position p is the
-    hull distance along the direction of the obstacle's centre m, so
+    inputs formed as in `reference_motion`; dist = `reference_distances`.  The
+    obstacle position p is that distance along the direction of the obstacle's centre m, so
     p . v = dist (m . w)/(|m||w|) and likewise p x v; the aspect is
     -(m . o)|m . o| / (|m|^2 |o|^2).  0 outside sensor range."""
     V = state.shape[1]
