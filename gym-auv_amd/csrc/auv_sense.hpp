@@ -497,7 +497,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
             double* pb = pobs + (el * P + q);
             pb[PB_X * pb_n] = X;  // advanced position, written back in phase 2
             pb[PB_Y * pb_n] = Y;
-            pb[PB_HEADING * pb_n] = a.poly_heading[ep];
+            // the heading column of the CPA index, or (RISK == 1) the ship's beam for the reference's distance
+            pb[PB_HEADING * pb_n] = RISK == 1 ? body_beam(vb, nv) : a.poly_heading[ep];
         }
         double ax = 0.0, ay = 0.0, ex = 0.0, ey = 0.0, nt = 0.0, dd = __builtin_inf();
         int cross = 0;
@@ -618,11 +619,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
         // the dist column and risk input of the reference's index: centre distance
         // less size less clearance; a ship's size is its beam (body-frame vertices
         // across its heading), a circle's its radius, i.e. the hull distance
-        auto ref_distance = [&](const double* ob, int el, int o, int e, double mx, double my) -> double {
+        auto ref_distance = [&](const double* ob, int el, int o, double mx, double my) -> double {
             if (o < C) return ob[OB_DIST * ob_n];
             const int nv = ecross[el * S + (o - C) * NV] >> 1;
-            const double* vb = a.poly_verts + ((size_t)e * P + (o - C)) * NV * 2;
-            return nv > 0 ? (__builtin_sqrt(mx * mx + my * my) - body_beam(vb, nv)) - a.vessel_radius : __builtin_inf();
+            const double beam = pobs[PB_HEADING * pb_n + (el * P + (o - C))];
+            return nv > 0 ? (__builtin_sqrt(mx * mx + my * my) - beam) - a.vessel_radius : __builtin_inf();
         };
         // when an env's obstacles sit in an aligned power-of-two group of lanes
         // of one wave, its nearest obstacle is a shuffle reduction
@@ -664,7 +665,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
                             hd = pb[PB_HEADING * pb_n];
                         }
                         a.obst_dist[eo] = dist;
-                        m[1] = RISK == 1 ? ref_distance(ob, el, o, e, mx, my) : dist;
+                        m[1] = RISK == 1 ? ref_distance(ob, el, o, mx, my) : dist;
                         if (RISK == 0) {
                             m[0] = hd;
                             m[2] = __builtin_sqrt(rvx * rvx + rvy * rvy);
@@ -673,8 +674,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
                         if (RISK == 1) {
                             const double* er = a.envrec + (size_t)e * ER_COUNT;
                             a.risk[eo] = risk_reference(mx, my, ov[0], ov[1], er[ER_VOX], er[ER_VOY],
-                                                        ref_distance(ob, el, o, e, mx, my), er[ER_COS], er[ER_SIN],
-                                                        a.state[2 * (size_t)V + e], range);
+                                                        ref_distance(ob, el, o, mx, my), er[ER_COS], er[ER_SIN],
+                                                        a.state[2 * (size_t)V + e], hull_distance(ob, el, o) < range);
                         } else {
                             a.risk[eo] = risk_index(mx, my, rvx, rvy, rvx * rvx + rvy * rvy, hull_distance(ob, el, o), range,
                                                     a.inv_range, a.w_d, a.w_c, a.t_c);

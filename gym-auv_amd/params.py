@@ -63,7 +63,7 @@ def make_config(n_envs: int, n_circles: int, n_polys: int, n_verts: int = 5,
                 n_rays: int = N_RAYS_DEFAULT, dt: float = 1.0,
                 sensor_range: float = SENSOR_RANGE_DEFAULT,
                 vessel_radius: float = 3.255, thrust_max: float = 2.0,
-                moment_max: float = 0.15, look_ahead: float = 100.0,
+                moment_max: float = 0.075, look_ahead: float = 100.0,
                 goal_radius: float = 5.0, max_steps: int = 10000,
                 risk=(0.4, 0.6, 60.0), reward=(1.0, 100.0, 100.0, 0.01)) -> dict:
     """Plain dict understood by `AuvSim` (device) and by the CPU oracle."""

@@ -171,7 +171,7 @@ static oc_ref_motion oc_reference_motion(double ovx, double ovy, double vox, dou
 
 /* oracle/ref_cri.py: risk_reference */
 static double oc_risk_reference(double mx, double my, double ovx, double ovy, double vox, double voy, double dist,
-                                double cpsi, double spsi, double psi, double range) {
+                                double cpsi, double spsi, double psi, int seen) {
     const oc_ref_motion rm = oc_reference_motion(ovx, ovy, vox, voy, cpsi, spsi, psi);
     const double mm = mx * mx + my * my;
     const double den = sqrt(mm * rm.ww);
@@ -185,7 +185,7 @@ static double oc_risk_reference(double mx, double my, double ovx, double ovy, do
     const double along = dist * ((mx * rm.wx + my * rm.wy) / dens);
     const double cross = dist * ((mx * rm.wy - my * rm.wx) / dens);
     const double r = oc_cri_terms(along, cross, moving, dist, b, aspect);
-    return dist < range ? r : 0.0;
+    return seen ? r : 0.0;   /* seen: hull within sensor range */
 }
 
 /* oracle/auv_oracle.py: vessel_rhs */
@@ -401,7 +401,7 @@ static void oc_sense_env(const oc_config *cf, const oc_buffers *b, int e, int is
         const double term_c = (w_c * (fc * fc)) * (t_c / (t_c + tcpa));
         const double rr = term_d + (has_c ? term_c : 0.0);
         b->risk[(size_t)e * O + o] = cf->risk_model == 1
-            ? oc_risk_reference(mx, my, vx, vy, vox, voy, dref, c, s, psi, range) : (inrange ? rr : 0.0);
+            ? oc_risk_reference(mx, my, vx, vy, vox, voy, dref, c, s, psi, dist[o] < range) : (inrange ? rr : 0.0);
     }
 
     /* navigation, flags, reward */

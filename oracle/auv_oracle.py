@@ -7,14 +7,17 @@ and observation assembly.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` may import it; the product path never
 does.
 
-PARITY UNPINNED for the sway-yaw block of the dynamics, obstacle advance, LiDAR,
-collision and the closest-point-of-approach risk index (the straight-line
-dynamics -- integrator, step, surge damping, thrust limit -- are pinned by
-samples of the reference's logs, tests/test_ref_surge_cpu.py): the reference checkout (hebe2602/gym-auv @ v1) does not
-contain the simulator (`radarCNN.py:232` only names the absent ``gym_auv/``
-package), so there is no reference function, golden vector or fixture to pin
-these against.  (The reference's own risk index, `ref_cri.py`, IS pinned: by
-every record of the reference's dataset files.)  What the
+PARITY UNPINNED for the LiDAR, the polygon hull distance and the collision
+predicate: the reference checkout (hebe2602/gym-auv @ v1) does not contain the
+simulator (`radarCNN.py:232` only names the absent ``gym_auv/`` package), so
+there is no reference function, golden vector or fixture to pin these against.
+PINNED by the reference's own log (data/metadata_MovingObstaclesNoRules.csv,
+data/risk_MovingObstaclesNoRules.csv), through fixtures under tests/golden/:
+the vessel dynamics (integrator, step, inertia, damping, couplings, thrust and
+moment limits: test_ref_surge_cpu.py, test_ref_turn_cpu.py), the integration of
+the position, the bearing and the circle distance (test_ref_track_cpu.py), the
+obstacle advance and every metadata column with the risk (ref_cri.py,
+test_ref_cri_cpu.py, test_ref_ship_cpu.py).  What the
 mounted files do constrain is restated here with citations:
 
 * scan width 180 and maximum range 150 m          -> utils/dataloader.py:13,56,127
@@ -567,7 +570,7 @@ class OracleEnv:
                                        self.obst_dist, cfg["vessel_radius"])
             self.meta = reference_metadata(self.state, self.circles, self.poly_pose, self.meta)
             self.meta[:, :, 1] = dref
-            self.risk = risk_reference(self.state, self.circles, self.poly_pose, dref, R)
+            self.risk = risk_reference(self.state, self.circles, self.poly_pose, dref, R, self.obst_dist)
         else:
             self.risk = risk_default(self.state, self.circles, self.poly_pose, self.obst_dist,
                                      R, cfg["risk"])

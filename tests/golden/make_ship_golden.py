@@ -45,13 +45,13 @@ def main():
     st = np.zeros((6, n))
     st[2], st[3:] = t["heading"][0], t["start"]
     track = [st.copy()]
-    act = np.stack([t["surge"], np.zeros(n)])
+    act = np.stack([t["surge"], t["steer"]])
     for _ in range(ROWS - 1):
         for _ in range(LOG_EVERY):
             st = orc.step_dynamics(st, act, cfg)
         track.append(st.copy())
 
-    out = {k: [] for k in ("row", "state", "surge", "heading_ts", "speed_ts", "offset", "records", "own", "risk")}
+    out = {k: [] for k in ("row", "state", "surge", "steer", "heading_ts", "speed_ts", "offset", "records", "own", "risk")}
     worst = 0.0
     for j in range(n):
         i = int(t["row"][j])
@@ -87,6 +87,7 @@ def main():
             out["row"].append(i)
             out["state"].append(track[0][:, j])
             out["surge"].append(t["surge"][j])
+            out["steer"].append(t["steer"][j])
             out["heading_ts"].append(h)
             out["speed_ts"].append(x[1])
             out["offset"].append(x[0])
@@ -99,7 +100,7 @@ def main():
           "; sizes", np.rint(size).min(), "..", np.rint(size).max())
     dst = os.path.join(HERE, "ship_golden.npz")
     np.savez_compressed(dst, row=np.array(out["row"], dtype=np.int32), state=np.array(out["state"]).T,
-                        **{k: np.array(out[k]) for k in ("surge", "heading_ts", "speed_ts", "offset", "records", "own", "risk")})
+                        **{k: np.array(out[k]) for k in ("surge", "steer", "heading_ts", "speed_ts", "offset", "records", "own", "risk")})
     print("wrote", dst)
 
 

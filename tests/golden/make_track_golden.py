@@ -15,7 +15,7 @@ constant and `bearing` the body-frame direction of the centre, then
 which is two equations for the single unknown K (obstacle radius plus whatever
 clearance the reference subtracts).  The script solves K by least squares for
 every pair of static records of two consecutive rows and keeps the pair when
-both equations are met to 1e-8 m: 700-odd obstacle sightings that pin, all at
+both equations are met to 1e-8 m: 5,230 obstacle sightings that pin, all at
 once, the integration of the position, the body-frame bearing and the
 centre-distance form of `dist`.  K - 3.255 is an integer between 18 and 45 for
 every one of them.  Data only: rows, the vessel state before, the command, the
@@ -35,8 +35,8 @@ LOG_EVERY = 5
 SURGE_RATIO = 0.678685866220174      # five RKF45 steps of u' = -(2/25.8) u, see make_surge_golden.py
 
 
-def advance(st, surge, cfg, steps=LOG_EVERY):
-    act = np.stack([surge, np.zeros_like(surge)])
+def advance(st, surge, steer, cfg, steps=LOG_EVERY):
+    act = np.stack([surge, steer])
     for _ in range(steps):
         st = orc.step_dynamics(st, act, cfg)
     return st
@@ -50,13 +50,14 @@ def main():
     cfg = importlib.import_module("gym-auv_amd.params").make_config(1, 0, 0)
 
     # segments (row A -> row A+1) with a known state at A and a known constant command
-    seg_row, seg_state, seg_surge = [], [], []
+    seg_row, seg_state, seg_surge, seg_steer = [], [], [], []
     g = np.load(os.path.join(HERE, "surge_golden.npz"))
     thrust = 2.0 * (g["speed_after"] - SURGE_RATIO * g["speed_before"]) / (1.0 - SURGE_RATIO)
     for i, psi, u, f in zip(g["row"], g["heading"], g["speed_before"], thrust):
         seg_row.append(int(i))
         seg_state.append([0.0, 0.0, psi, u, 0.0, 0.0])
         seg_surge.append(min(max(f / 2.0, 0.0), 1.0))
+        seg_steer.append(0.0)
     t = np.load(os.path.join(HERE, "turn_golden.npz"))
     n = t["start"].shape[1]
     st = np.zeros((6, n))
@@ -66,16 +67,18 @@ def main():
             seg_row.append(int(t["row"][j]) + k)
             seg_state.append([0.0, 0.0, t["heading"][k][j], st[3][j], st[4][j], st[5][j]])
             seg_surge.append(float(t["surge"][j]))
-        st = advance(st, t["surge"], cfg)
+            seg_steer.append(float(t["steer"][j]))
+        st = advance(st, t["surge"], t["steer"], cfg)
     # windows overlap: keep one segment per row
     _, first = np.unique(np.array(seg_row), return_index=True)
     seg_row = np.array(seg_row)[first]
     A = np.array(seg_state)[first].T.copy()
     surge = np.array(seg_surge)[first]
-    B = advance(A.copy(), surge, cfg)
+    steer = np.array(seg_steer)[first]
+    B = advance(A.copy(), surge, steer, cfg)
     dp = B[:2] - A[:2]
 
-    out = {k: [] for k in ("row", "state", "surge", "dist_a", "bearing_a", "dist_b", "bearing_b", "offset")}
+    out = {k: [] for k in ("row", "state", "surge", "steer", "dist_a", "bearing_a", "dist_b", "bearing_b", "offset")}
     for s, i in enumerate(seg_row):
         a, b = rows[i], rows[i + 1]
         stat_a = [a[2 + 5 * o:7 + 5 * o] for o in range((len(a) - 2) // 5) if a[2 + 5 * o] == 0 and a[4 + 5 * o] == a[0]]
@@ -93,6 +96,7 @@ def main():
                     out["row"].append(i)
                     out["state"].append(A[:, s])
                     out["surge"].append(surge[s])
+                    out["steer"].append(steer[s])
                     out["dist_a"].append(ra[1])
                     out["bearing_a"].append(ra[3])
                     out["dist_b"].append(rb[1])
@@ -104,7 +108,7 @@ def main():
           "; radii", np.rint(K - 3.255).min(), "..", np.rint(K - 3.255).max())
     dst = os.path.join(HERE, "track_golden.npz")
     np.savez_compressed(dst, row=np.array(out["row"], dtype=np.int32), state=np.array(out["state"]).T,
-                        **{k: np.array(out[k]) for k in ("surge", "dist_a", "bearing_a", "dist_b", "bearing_b", "offset")})
+                        **{k: np.array(out[k]) for k in ("surge", "steer", "dist_a", "bearing_a", "dist_b", "bearing_b", "offset")})
     print("wrote", dst)
 
 

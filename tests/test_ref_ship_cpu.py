@@ -3,7 +3,7 @@ columns and the risk, through the simulation.
 
 `tests/golden/ship_golden.npz` (made by make_ship_golden.py from
 data/metadata_MovingObstaclesNoRules.csv and risk_MovingObstaclesNoRules.csv)
-holds 121 moving obstacles, each logged in 4 consecutive rows through which the
+holds 134 moving obstacles, each logged in 4 consecutive rows through which the
 vessel's state and command are known (windows of turn_golden.npz).  Per
 obstacle the fixture carries its heading, its speed s and its size (the
 constant K - 3.255 the reference subtracts from the centre distance; an integer
@@ -12,7 +12,7 @@ constant K - 3.255 the reference subtracts from the centre distance; an integer
 Here one env per obstacle gets a ship of that beam where the first row saw it,
 sailing along its heading at s, and the vessel runs the 15 steps.  At every
 logged row the env's metadata record [heading_ts, dist, speed, bearing, course]
-(utils/explore_dataset.py:45) and its risk have to be the logged ones: 363 rows
+(utils/explore_dataset.py:45) and its risk have to be the logged ones: 402 rows
 x 6 numbers that test the obstacle advance, the vessel track, the reference's
 conventions for every column and its risk index as evaluated inside the step."""
 import os
@@ -72,7 +72,7 @@ def check_row(g, k, own, meta, risk):
 def test_fixture_shape_and_integer_sizes():
     g = ships()
     n = len(g["offset"])
-    assert n == 121 and g["records"].shape == (n, ROWS, 5) and g["risk"].shape == (n, ROWS)
+    assert n == 134 and g["records"].shape == (n, ROWS, 5) and g["risk"].shape == (n, ROWS)
     size = g["offset"] - 3.255
     assert np.abs(size - np.rint(size)).max() < 1e-9 and np.rint(size).min() == 3 and np.rint(size).max() == 18
     assert g["speed_ts"].min() > 0.05 and g["speed_ts"].max() < 1.3
@@ -89,7 +89,7 @@ def test_numpy_oracle_reproduces_the_logged_ship_records():
     env.set_path(scene["path"])
     env.reset(g["state"].copy())
     check_row(g, 0, env.own, env.meta, env.risk)
-    act = np.stack([g["surge"], np.zeros(n)])
+    act = np.stack([g["surge"], g["steer"]])
     for k in range(1, ROWS):
         for _ in range(LOG_EVERY):
             env.step(act)
@@ -105,7 +105,7 @@ def test_c_oracle_reproduces_the_logged_ship_records():
     env.set_scene(scene["circles"], scene["poly_pose"], scene["poly_verts"], scene["poly_nv"], scene["poly_heading"])
     env.set_path(scene["path"])
     env.reset(g["state"].copy())
-    act = np.stack([g["surge"], np.zeros(n)])
+    act = np.stack([g["surge"], g["steer"]])
     for k in range(1, ROWS):
         for _ in range(LOG_EVERY):
             env.step(act)

@@ -2,7 +2,7 @@
 own data.
 
 `tests/golden/track_golden.npz` (made by make_track_golden.py from
-data/metadata_MovingObstaclesNoRules.csv) holds 4,886 sightings of a static
+data/metadata_MovingObstaclesNoRules.csv) holds 5,230 sightings of a static
 obstacle in two consecutive logged rows between which the vessel's state and
 command are known (the rows covered by surge_golden.npz and turn_golden.npz).
 Each is a sample of three things at once: how the reference integrates the
@@ -62,7 +62,7 @@ def check(g, obst_dist, meta, collision):
 def test_fixture_shape_and_integer_radii():
     g = sightings()
     n = len(g["offset"])
-    assert n == 4886 and g["state"].shape == (6, n)
+    assert n == 5230 and g["state"].shape == (6, n)
     radius = g["offset"] - 3.255
     assert np.abs(radius - np.rint(radius)).max() < 1e-7
     assert np.rint(radius).min() == 15 and np.rint(radius).max() == 41
@@ -82,7 +82,7 @@ def test_numpy_oracle_tracks_the_reference_obstacles():
     # before the first step the env reports row A's numbers
     assert np.abs(env.obst_dist[:, 0] - g["dist_a"]).max() <= 1e-10
     assert np.abs(O.wrap_angle(env.meta[:, 0, 3] - g["bearing_a"])).max() <= 1e-12
-    act = np.stack([g["surge"], np.zeros(n)])
+    act = np.stack([g["surge"], g["steer"]])
     for _ in range(LOG_EVERY):
         env.step(act)
     check(g, env.obst_dist, env.meta, env.collision)
@@ -97,7 +97,7 @@ def test_c_oracle_tracks_the_reference_obstacles():
     env.set_scene(scene["circles"], scene["poly_pose"], np.zeros((n, 0, 1, 2)), scene["poly_nv"], None)
     env.set_path(scene["path"])
     env.reset(g["state"].copy())
-    act = np.stack([g["surge"], np.zeros(n)])
+    act = np.stack([g["surge"], g["steer"]])
     for _ in range(LOG_EVERY):
         env.step(act)
     check(g, env.obst_dist, env.meta, env.collision)

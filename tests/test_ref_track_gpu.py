@@ -1,5 +1,5 @@
 """The device's position integration, obstacle distance and bearing against the
-reference's own data, through the C ABI: 4,886 sightings of static obstacles in
+reference's own data, through the C ABI: 5,230 sightings of static obstacles in
 consecutive rows of the reference's log (`tests/golden/track_golden.npz`; see
 tests/test_ref_track_cpu.py for what they pin).  One env per sighting, 5 steps
 with the logged command, on both sensing paths; dist and bearing afterwards are
@@ -21,7 +21,7 @@ def test_device_tracks_the_reference_obstacles(mode):
     cfg = params.make_config(n, 1, 0)
     sim = make_sim(cfg, scene_for(g, cfg), lidar_mode=mode)
     sim.reset(g["state"].copy())
-    act = np.stack([g["surge"], np.zeros(n)])
+    act = np.stack([g["surge"], g["steer"]])
     for _ in range(LOG_EVERY):
         sim.step_host(act)
     check(g, sim.read("obst_dist"), sim.read("meta"), sim.read("collision"))

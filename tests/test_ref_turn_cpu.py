@@ -3,15 +3,16 @@
 The reference's simulator is not in its checkout, but its dataset logs
 [speed_OS, heading_OS] once per 5 simulator steps
 (data/metadata_MovingObstaclesNoRules.csv; utils/explore_dataset.py:8).
-`tests/golden/turn_golden.npz` (made by make_turn_golden.py) holds the 1,822
+`tests/golden/turn_golden.npz` (made by make_turn_golden.py) holds the 1,957
 windows of 4 consecutive rows (a fifth of the log) through which the vessel
-turned with the rudder at zero and the thruster at a limit (238 coasting, 1,584
-at full thrust): 7 logged numbers (4 speeds, 3 heading changes) that depend on 3
+turned with the thruster at a limit and the rudder at zero (238 coasting, 1,584
+at full thrust) or hard over (135): 7 logged numbers (4 speeds, 3 heading changes) that depend on 3
 unknowns only, the body velocities (u, v, r) at the first row, which the fixture
 carries as `start`.  Integrating 15 steps from that start has to give back all
 7 numbers, to 1e-13 (the logs are met to 3e-15): this pins the inertia matrix of
 the sway-yaw block, its linear damping and the velocity-dependent coupling
-(m u r in sway, m x_g u r in yaw, none in surge).  A textbook Coriolis matrix
+(m u r in sway, m x_g u r in yaw, none in surge) and, through the hard-over
+windows, the yaw moment limit of 0.075 N m acting on yaw alone.  A textbook Coriolis matrix
 with added mass in it misses the same numbers in the 3rd digit."""
 import os
 
@@ -28,7 +29,7 @@ ROWS, LOG_EVERY = 4, 5
 
 def windows():
     g = np.load(GOLDEN)
-    return g["start"], g["speed"], g["heading"], g["surge"]
+    return g["start"], g["speed"], g["heading"], np.stack([g["surge"], g["steer"]])
 
 
 def compare(states, speed, heading):
@@ -41,22 +42,25 @@ def compare(states, speed, heading):
 
 
 def test_fixture_is_over_determined_and_not_trivial():
-    start, speed, heading, surge = windows()
-    n = 1822
+    start, speed, heading, cmd = windows()
+    n = 1957
     assert start.shape == (3, n) and speed.shape == (ROWS, n) and heading.shape == (ROWS, n)
-    assert (surge == 0.0).sum() == 238 and (surge == 1.0).sum() == 1584
+    surge, steer = cmd
+    assert ((surge == 0.0) & (steer == 0.0)).sum() == 238 and ((surge == 1.0) & (steer == 0.0)).sum() == 1584
+    assert (steer == 1.0).sum() == 65 and (steer == -1.0).sum() == 70      # rudder hard over: the moment limit
+    assert params.make_config(1, 0, 0)["moment_max"] == 0.075
     turn = np.abs(O.wrap_angle(heading[-1] - heading[0]))
     assert (turn > 1e-2).sum() >= 500 and turn.max() > 0.4         # real turns, up to 24 degrees per window
     assert np.abs(start[1]).max() > 0.15 and np.abs(start[2]).max() > 0.1   # sway 0.18 m/s, yaw rate 0.1 rad/s
 
 
 def test_numpy_oracle_reproduces_the_reference_turns():
-    start, speed, heading, surge = windows()
+    start, speed, heading, cmd = windows()
     n = start.shape[1]
     cfg = params.make_config(n, 0, 0)
     s = np.zeros((6, n))
     s[2], s[3:] = heading[0], start
-    act = np.stack([surge, np.zeros(n)])
+    act = cmd
     states = [s]
     for _ in range(ROWS - 1):
         for _ in range(LOG_EVERY):
@@ -68,7 +72,7 @@ def test_numpy_oracle_reproduces_the_reference_turns():
 
 def test_textbook_coriolis_matrix_does_not_fit_the_reference_turns():
     """Guards the pin: the same windows reject M_A-based Coriolis terms."""
-    start, speed, heading, surge = windows()
+    start, speed, heading, cmd = windows()
     n = start.shape[1]
     cfg = params.make_config(n, 0, 0)
     mp = cfg["model"]
@@ -78,9 +82,9 @@ def test_textbook_coriolis_matrix_does_not_fit_the_reference_turns():
         psi, u, v, r = y[2], y[3], y[4], y[5]
         c13 = -(m22 * v + m23 * r)
         c23 = m11 * u
-        r1 = (2.0 * surge - c13 * r) - 2.0 * u
+        r1 = (2.0 * cmd[0] - c13 * r) - 2.0 * u
         r2 = -(c23 * r) - (7.0 * v + 0.1 * r)
-        r3 = -(-(c13 * u) - c23 * v) - (0.1 * v + 0.5 * r)
+        r3 = (0.075 * cmd[1] - (-(c13 * u) - c23 * v)) - (0.1 * v + 0.5 * r)
         return np.stack([np.cos(psi) * u - np.sin(psi) * v, np.sin(psi) * u + np.cos(psi) * v, r,
                          mp[O.MP_MINV11] * r1, mp[O.MP_MINV22] * r2 + mp[O.MP_MINV23] * r3,
                          mp[O.MP_MINV32] * r2 + mp[O.MP_MINV33] * r3])
@@ -101,7 +105,7 @@ def test_textbook_coriolis_matrix_does_not_fit_the_reference_turns():
 
 
 def test_c_oracle_reproduces_the_reference_turns():
-    start, speed, heading, surge = windows()
+    start, speed, heading, cmd = windows()
     n = start.shape[1]
     cfg = params.make_config(n, 0, 0)
     env = c_oracle.COracleEnv(cfg, params.ray_table(cfg["n_rays"]))
@@ -112,7 +116,7 @@ def test_c_oracle_reproduces_the_reference_turns():
     init = np.zeros((6, n))
     init[2], init[3:] = heading[0], start
     env.reset(init)
-    act = np.stack([surge, np.zeros(n)])
+    act = cmd
     states = [init]
     for _ in range(ROWS - 1):
         for _ in range(LOG_EVERY):

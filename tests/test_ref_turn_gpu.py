@@ -1,7 +1,7 @@
 """The device's sway-yaw dynamics against the reference's own data, through the
-C ABI: 1,822 rudder-free turns of the reference simulator
+C ABI: 1,957 turns of the reference simulator
 (`tests/golden/turn_golden.npz`; see tests/test_ref_turn_cpu.py for what they
-pin).  One env per window, 15 steps with the window's thrust command from its start;
+pin).  One env per window, 15 steps with the window's command from its start;
 speed and heading at every logged row have to be the ones the reference logged,
 to 1e-13, on both stepping paths, and the logged columns (`own`) carry them."""
 import numpy as np
@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["fused", "allpairs"])
 def test_device_reproduces_the_reference_turns(mode):
-    start, speed, heading, surge = windows()
+    start, speed, heading, cmd = windows()
     n = start.shape[1]
     cfg = params.make_config(n, 0, 0)
     path = np.zeros((n, 6))
@@ -28,7 +28,7 @@ def test_device_reproduces_the_reference_turns(mode):
     init = np.zeros((6, n))
     init[2], init[3:] = heading[0], start
     sim.reset(init)
-    act = np.stack([surge, np.zeros(n)])
+    act = cmd
     states = [init]
     for k in range(1, ROWS):
         for _ in range(LOG_EVERY):
