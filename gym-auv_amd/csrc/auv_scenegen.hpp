@@ -60,6 +60,7 @@ struct SceneGenArgs {
     double* poly_verts;         // [V,P,NV,2]
     int32_t* poly_nv;
     double* poly_heading;
+    double* poly_beam;
     double* path;  // [V,6]
     double* init;  // [6,V]
     double extent, r_lo, r_hi, w_lo, w_hi, s_lo, s_hi, clearance, path_length;
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256) void k_scenegen(SceneGenArgs a) {
         for (int k = 10; k < 2 * NV; ++k) v[k] = 0.0;
         a.poly_nv[ep_i] = 5;
         a.poly_heading[ep_i] = h;
+        a.poly_beam[ep_i] = hw - (-hw);
     }
 }
 

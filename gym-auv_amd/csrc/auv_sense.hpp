@@ -162,6 +162,7 @@ struct SenseArgs {
     const double* poly_verts;
     const int32_t* poly_nv;
     const double* poly_heading;
+    const double* poly_beam;  // [V,P]
     const double* ray_dirs;
     double* ranges;
     int32_t* hit;
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
             pb[PB_X * pb_n] = X;  // advanced position, written back in phase 2
             pb[PB_Y * pb_n] = Y;
             // the heading column of the CPA index, or (RISK == 1) the ship's beam for the reference's distance
-            pb[PB_HEADING * pb_n] = RISK == 1 ? body_beam(vb, nv) : a.poly_heading[ep];
+            pb[PB_HEADING * pb_n] = RISK == 1 ? a.poly_beam[ep] : a.poly_heading[ep];
         }
         double ax = 0.0, ay = 0.0, ex = 0.0, ey = 0.0, nt = 0.0, dd = __builtin_inf();
         int cross = 0;

@@ -59,6 +59,7 @@ struct auv_sim {
     double* poly_verts = nullptr;
     int32_t* poly_nv = nullptr;
     double* poly_heading = nullptr;
+    double* poly_beam = nullptr;  // [V,P] extent of the body-frame vertices across the heading (a scene constant)
     double* path = nullptr;
     double* ray_dirs = nullptr;
     double* init_stage = nullptr;  // [6,V] staging for reset
@@ -224,6 +225,7 @@ int launch_scenegen(auv_sim* h, hipStream_t st, const uint8_t* only_done) {
     ga.poly_verts = h->poly_verts;
     ga.poly_nv = h->poly_nv;
     ga.poly_heading = h->poly_heading;
+    ga.poly_beam = h->poly_beam;
     ga.path = h->path;
     ga.init = h->init_stage;
     const auv_scene_params& p = h->gen_params;
@@ -323,6 +325,7 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.poly_verts = h->poly_verts;
     sa.poly_nv = h->poly_nv;
     sa.poly_heading = h->poly_heading;
+    sa.poly_beam = h->poly_beam;
     sa.ray_dirs = h->ray_dirs;
     sa.ranges = bp<double>(h, AUV_BUF_RANGES);
     sa.hit = bp<int32_t>(h, AUV_BUF_HIT);
@@ -595,6 +598,7 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     chk(alloc_raw(h, &h->poly_verts, (size_t)V * P * NV * 2));
     chk(alloc_raw(h, &h->poly_nv, (size_t)V * P));
     chk(alloc_raw(h, &h->poly_heading, (size_t)V * P));
+    chk(alloc_raw(h, &h->poly_beam, (size_t)V * P));
     chk(alloc_raw(h, &h->path, (size_t)V * 6));
     chk(alloc_raw(h, &h->ray_dirs, (size_t)R * 2));
     chk(alloc_raw(h, &h->init_stage, (size_t)V * 6));
@@ -629,7 +633,7 @@ void auv_destroy(auv_handle h) {
     for (auto& ev : h->events) (void)hipEventDestroy(ev);
     for (auto& b : h->buf)
         if (b.ptr) (void)hipFree(b.ptr);
-    void* raw[] = {h->poly_verts, h->poly_nv, h->poly_heading, h->path, h->ray_dirs, h->init_stage, h->mask_stage,
+    void* raw[] = {h->poly_verts, h->poly_nv, h->poly_heading, h->poly_beam, h->path, h->ray_dirs, h->init_stage, h->mask_stage,
                    h->circles0, h->poly_pose0, h->envrec, h->cnn_w};
     for (void* p : raw)
         if (p) (void)hipFree(p);
@@ -679,6 +683,18 @@ int auv_set_scene(auv_handle h, int32_t env_begin, int32_t env_count, const doub
         HIP_TRY(h, hipMemcpy(h->poly_nv + b * d.P, poly_nv, n * d.P * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(h->poly_heading + b * d.P, poly_heading, n * d.P * sizeof(double),
                              hipMemcpyHostToDevice));
+        // beam of every ship: max - min of the body-frame y of its vertices
+        std::vector<double> beam(n * d.P, 0.0);
+        for (size_t i = 0; i < n * d.P; ++i) {
+            double hi = -INFINITY, lo = INFINITY;
+            for (int k = 0; k < poly_nv[i]; ++k) {
+                const double y = poly_verts[(i * d.NV + k) * 2 + 1];
+                hi = y > hi ? y : hi;
+                lo = y < lo ? y : lo;
+            }
+            if (poly_nv[i] > 0) beam[i] = hi - lo;
+        }
+        HIP_TRY(h, hipMemcpy(h->poly_beam + b * d.P, beam.data(), n * d.P * sizeof(double), hipMemcpyHostToDevice));
     }
     if (path) HIP_TRY(h, hipMemcpy(h->path + b * 6, path, n * 6 * sizeof(double), hipMemcpyHostToDevice));
     // the scene counts as complete once one call has covered all envs, or the
