@@ -61,14 +61,18 @@ typedef struct auv_config {
     int32_t reserved;
     double dt;              /* integrator step, s */
     double sensor_range;    /* 150 m: utils/dataloader.py:56 */
-    double vessel_radius;
-    double thrust_max;
-    double moment_max;
+    double vessel_radius;   /* clearance taken off every obstacle distance, m (3.255: what the reference's logged
+                               dist column subtracts beside the obstacle's size) */
+    double thrust_max;      /* surge force at action[0] = 1, N (2: the reference's logs saturate there) */
+    double moment_max;      /* yaw moment at action[1] = +-1, N m (0.075: likewise) */
     double look_ahead;
     double goal_radius;
     double risk[3];         /* w_d, w_c, T_c of the AUV_RISK_CPA index */
     double reward[4];       /* w_progress, w_collision, w_goal, w_cross_track */
-    double model[AUV_N_MODEL];
+    double model[AUV_N_MODEL]; /* Minv11, Minv22, Minv23, Minv32, Minv33 (inverse inertia incl. added mass), m, m*x_g,
+                                  reserved (0), Xu, Xuu, Yv, Yvv, Yr, Nv, Nr, Nrr (damping, positive):
+                                  nu' = Minv (tau - [(Xu+Xuu|u|)u, (Yv+Yvv|v|)v + (m u + Yr) r,
+                                  Nv v + (m x_g u + Nr + Nrr|r|) r]) */
 } auv_config;
 
 typedef enum auv_dtype { AUV_F64 = 0, AUV_F32 = 1, AUV_I32 = 2, AUV_U8 = 3, AUV_I64 = 4 } auv_dtype;
