@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void k_encounter(EncArgs a) {
         const double fc = 1.0 - (dcpa < R ? dcpa : R) / R;
         const double term_c = (a.w_c * (fc * fc)) * (a.t_c / (a.t_c + tcpa));
         const double rr = term_d + (has_c ? term_c : 0.0);
-        a.risk[eo] = a.risk_model == 1 ? risk_reference(mx, my, vx, vy, vox, voy, dref, sc.c, sc.s, psi, dist < R) : (inrange ? rr : 0.0);
+        a.risk[eo] = a.risk_model == 1 ? risk_reference(mx, my, vx, vy, vox, voy, dref, sc.c, sc.s, psi, dref < __builtin_inf()) : (inrange ? rr : 0.0);
     }
     __syncthreads();
     for (int el = threadIdx.x; el < ne; el += blockDim.x) {

@@ -117,10 +117,11 @@ __device__ __forceinline__ RefMotion reference_motion(double ovx, double ovy, do
 // ovy) the obstacle's velocity, (vox, voy) the vessel's, dist the reference's
 // distance (centre distance less size less clearance), psi the vessel's heading
 // with its cosine and sine.  The obstacle position is dist along m, so
-// p . v = dist (m . w)/(|m||w|).  S half; -inf for an obstacle that is not
-// seen (hull outside sensor range), which makes the clipped sum 0.
+// p . v = dist (m . w)/(|m||w|).  S half; -inf for an absent slot (!present),
+// which makes the clipped sum 0.  Every present obstacle has a risk, whatever
+// its distance.
 __device__ __forceinline__ double risk_reference_s(double mx, double my, double ovx, double ovy, double vox, double voy,
-                                                   double dist, double cpsi, double spsi, double psi, bool seen) {
+                                                   double dist, double cpsi, double spsi, double psi, bool present) {
     const RefMotion rm = reference_motion(ovx, ovy, vox, voy, cpsi, spsi, psi);
     const double mm = mx * mx + my * my;
     const double den = __builtin_sqrt(mm * rm.ww);
@@ -129,7 +130,7 @@ __device__ __forceinline__ double risk_reference_s(double mx, double my, double 
     const double along = dist * ((mx * rm.wx + my * rm.wy) / dens);
     const double cross = dist * ((mx * rm.wy - my * rm.wx) / dens);
     const double s_half = cri_cpa_range_half(along, cross, moving, dist);
-    return seen ? s_half : 0.0 - __builtin_inf();
+    return present ? s_half : 0.0 - __builtin_inf();
 }
 
 // T half from the body bearing b = wrap(atan2(m) - psi); the aspect is
@@ -143,9 +144,9 @@ __device__ __forceinline__ double risk_reference_t(double mx, double my, double 
 }
 
 __device__ __forceinline__ double risk_reference(double mx, double my, double ovx, double ovy, double vox, double voy,
-                                                 double dist, double cpsi, double spsi, double psi, bool seen) {
+                                                 double dist, double cpsi, double spsi, double psi, bool present) {
     const double b = wrap_angle(atan2_det(my, mx) - psi);
-    return cri_sum(risk_reference_s(mx, my, ovx, ovy, vox, voy, dist, cpsi, spsi, psi, seen),
+    return cri_sum(risk_reference_s(mx, my, ovx, ovy, vox, voy, dist, cpsi, spsi, psi, present),
                    risk_reference_t(mx, my, ovx, ovy, b));
 }
 

@@ -674,9 +674,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
                     } else if (task == 3) {
                         if (RISK == 1) {
                             const double* er = a.envrec + (size_t)e * ER_COUNT;
-                            a.risk[eo] = risk_reference(mx, my, ov[0], ov[1], er[ER_VOX], er[ER_VOY],
-                                                        ref_distance(ob, el, o, mx, my), er[ER_COS], er[ER_SIN],
-                                                        a.state[2 * (size_t)V + e], hull_distance(ob, el, o) < range);
+                            const double dref = ref_distance(ob, el, o, mx, my);
+                            a.risk[eo] = risk_reference(mx, my, ov[0], ov[1], er[ER_VOX], er[ER_VOY], dref, er[ER_COS],
+                                                        er[ER_SIN], a.state[2 * (size_t)V + e], dref < __builtin_inf());
                         } else {
                             a.risk[eo] = risk_index(mx, my, rvx, rvy, rvx * rvx + rvy * rvy, hull_distance(ob, el, o), range,
                                                     a.inv_range, a.w_d, a.w_c, a.t_c);

@@ -185,7 +185,7 @@ static double oc_risk_reference(double mx, double my, double ovx, double ovy, do
     const double along = dist * ((mx * rm.wx + my * rm.wy) / dens);
     const double cross = dist * ((mx * rm.wy - my * rm.wx) / dens);
     const double r = oc_cri_terms(along, cross, moving, dist, b, aspect);
-    return seen ? r : 0.0;   /* seen: hull within sensor range */
+    return seen ? r : 0.0;   /* seen: the slot holds an obstacle */
 }
 
 /* oracle/auv_oracle.py: vessel_rhs */
@@ -401,7 +401,7 @@ static void oc_sense_env(const oc_config *cf, const oc_buffers *b, int e, int is
         const double term_c = (w_c * (fc * fc)) * (t_c / (t_c + tcpa));
         const double rr = term_d + (has_c ? term_c : 0.0);
         b->risk[(size_t)e * O + o] = cf->risk_model == 1
-            ? oc_risk_reference(mx, my, vx, vy, vox, voy, dref, c, s, psi, dist[o] < range) : (inrange ? rr : 0.0);
+            ? oc_risk_reference(mx, my, vx, vy, vox, voy, dref, c, s, psi, dref < INFINITY) : (inrange ? rr : 0.0);
     }
 
     /* navigation, flags, reward */

@@ -570,7 +570,7 @@ class OracleEnv:
                                        self.obst_dist, cfg["vessel_radius"])
             self.meta = reference_metadata(self.state, self.circles, self.poly_pose, self.meta)
             self.meta[:, :, 1] = dref
-            self.risk = risk_reference(self.state, self.circles, self.poly_pose, dref, R, self.obst_dist)
+            self.risk = risk_reference(self.state, self.circles, self.poly_pose, dref)
         else:
             self.risk = risk_default(self.state, self.circles, self.poly_pose, self.obst_dist,
                                      R, cfg["risk"])

@@ -214,13 +214,14 @@ def reference_metadata(state, circles, poly_pose, meta):
     return out
 
 
-def risk_reference(state, circles, poly_pose, dist, sensor_range, hull_dist=None):
+def risk_reference(state, circles, poly_pose, dist):
     """Per-obstacle risk [V, C+P] of a simulator state with the index above;
     inputs formed as in `reference_motion`; dist = `reference_distances`.  The
     obstacle position p is that distance along the direction of the obstacle's centre m, so
     p . v = dist (m . w)/(|m||w|) and likewise p x v; the aspect is
-    -(m . o)|m . o| / (|m|^2 |o|^2).  0 for an obstacle whose hull (`hull_dist`,
-    default `dist`) is outside sensor range."""
+    -(m . o)|m . o| / (|m|^2 |o|^2).  Every present obstacle has a risk, whatever
+    its distance (the reference logs risks of up to 0.41 for obstacles beyond its
+    sensor range); absent slots (dist = +inf) have 0."""
     V = state.shape[1]
     px, py, psi = state[0], state[1], state[2]
     vox, voy = _own_velocity(state)
@@ -244,6 +245,5 @@ def risk_reference(state, circles, poly_pose, dist, sensor_range, hull_dist=None
             along = d * ((mx * wx + my * wy) / dens)
             cross = d * ((mx * wy - my * wx) / dens)
             r = cri_terms(along, cross, moving, d, b, aspect)
-        gate = d if hull_dist is None else hull_dist[:, o]
-        risk[:, o] = np.where(gate < sensor_range, r, 0.0)
+        risk[:, o] = np.where(d < np.inf, r, 0.0)
     return risk

@@ -91,7 +91,7 @@ def test_state_form_reproduces_the_reference_too():
     circles[:, 0, 3] = so[keep] * np.cos(g["heading_ts"][keep])
     circles[:, 0, 4] = so[keep] * np.sin(g["heading_ts"][keep])
     dist = g["dist"][keep][:, None]
-    got = ref_cri.risk_reference(state, circles, np.zeros((n, 0, 6)), dist, np.inf)[:, 0]
+    got = ref_cri.risk_reference(state, circles, np.zeros((n, 0, 6)), dist)[:, 0]
     err = np.abs(got - g["risk"][keep])
     # looser than the record form: bearing, course and speed_ts are recomputed here
     assert err.max() < 1e-9, f"max {err.max()} at {int(err.argmax())}"
