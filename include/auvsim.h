@@ -85,7 +85,7 @@ typedef enum auv_buffer {
     AUV_BUF_HIT = 3,         /* i32 [V,R]   obstacle id, -1 when nothing hit */
     AUV_BUF_PERCEPTION = 4,  /* f32 [V,1,R] obs["perception"], radarCNN.py:275 */
     AUV_BUF_NAVIGATION = 5,  /* f32 [V,1,6] obs["navigation"], radarCNN.py:190-193 */
-    AUV_BUF_OBST_DIST = 6,   /* f64 [V,O]   signed hull distance, +inf if absent */
+    AUV_BUF_OBST_DIST = 6,   /* f64 [V,O]   signed hull distance less vessel_radius, +inf if absent */
     AUV_BUF_RISK = 7,        /* f64 [V,O]   risk_*.csv values, utils/dataloader.py:108 */
     AUV_BUF_META = 8,        /* f64 [V,O,5] utils/explore_dataset.py:45 */
     AUV_BUF_OWN = 9,         /* f64 [V,2]   speed_OS, heading_OS, utils/explore_dataset.py:8 */
