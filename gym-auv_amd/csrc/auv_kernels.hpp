@@ -3,7 +3,7 @@
 //
 //   k_dynamics   one thread per vessel: RKF45 step of the 3-DOF model on SoA
 //                fp64 state (coalesced 8-B lanes); the same launch advances
-//                the constant-velocity obstacles.  HBM-bound, 112 B / vessel.
+//                the constant-velocity obstacles.  112 B / vessel; latency-sized.
 //   k_encounter  one thread per (env, obstacle): signed hull distance,
 //                encounter metadata, risk; then one thread per env: collision
 //                flag, nearest obstacle, navigation features, done flags.

@@ -6,8 +6,10 @@
 //
 //   risk = max(0, 0.2 u_B(bearing) + 0.3 u_DCPA u_TCPA + 0.3 u_D(dist) + 0.2 u_A)
 //
-// p is the obstacle position (hull distance along the world-frame direction
-// of the obstacle), v the unit direction of the relative course as the
+// dist is the reference's distance column: centre distance less the obstacle's
+// size (a circle's radius, a ship's beam) less a clearance.  p is the obstacle
+// position (dist along the world-frame direction of the obstacle's centre), v
+// the unit direction of the relative course as the
 // reference forms it, u_A = cos(a)|cos(a)| of the vessel's bearing a seen from
 // a moving obstacle relative to that obstacle's heading (0 for a static one).
 // Unfused fp64 in this operation order: bit-equal to the numpy and C
