@@ -24,6 +24,8 @@ ncp, nep = raw[:, 0, 14], raw[:, 0, 15]
 tot = ncp + nep
 print("pairs per block: circle mean %.0f edge mean %.0f total mean %.0f p50 %d p90 %d p99 %d max %d; >1024: %.3f" % (
     ncp.mean(), nep.mean(), tot.mean(), *np.percentile(tot, [50, 90, 99]), tot.max(), (tot > 1024).mean()))
+ok = (raw[:, :, 5] != 0).all(axis=1)          # blocks whose pair list fitted (the others skip stamps 5..8)
+raw = raw[ok]
 s = raw[:, :, :10].astype(np.float64)
 d = np.diff(s, axis=2)
 names = ["P0 init", "P1 stage", "bar1", "P2 obst", "sweep0", "bar2", "sweep1", "bar3", "output"]
