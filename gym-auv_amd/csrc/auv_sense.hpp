@@ -152,6 +152,8 @@ __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
 struct SenseArgs {
     Dims d;
     int TE;       // envs per workgroup
+    int lds[12];  // byte offsets of the LDS arrays (sense_layout, computed once on the host): env, circ, seg,
+                  // best, obst, edist, meta, offs, ids, pairs, ecross, wsum
     int cap;      // pair-list slots per round
     int is_step;  // 1: advance obstacles, finish the reward; 0: after reset / plain sense
     int with_meta;  // 0: bearing, course and risk of the obstacles are not refreshed by this pass
@@ -353,7 +355,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
     const int S = P * NV;
     const int TE = a.TE;
     const int cap = a.cap;
-    const SenseLayout L = sense_layout(TE, R, C, P, NV, cap, a.cnn_w ? a.cnn_kind : -1);
+    struct { int env, circ, seg, best, obst, edist, meta, offs, ids, pairs, ecross, wsum; } L = {
+        a.lds[0], a.lds[1], a.lds[2], a.lds[3], a.lds[4], a.lds[5], a.lds[6], a.lds[7], a.lds[8], a.lds[9], a.lds[10], a.lds[11]};
     double* env = reinterpret_cast<double*>(lds_raw + L.env);
     double* circ = reinterpret_cast<double*>(lds_raw + L.circ);
     double* seg = reinterpret_cast<double*>(lds_raw + L.seg);

@@ -353,6 +353,11 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.cnn_w = cnn_inside ? h->cnn_w : nullptr;
     sa.cnn_out = bp<float>(h, AUV_BUF_CNN_OUT);
     sa.cnn_kind = h->cnn_kind;
+    {
+        const SenseLayout L = sense_layout(sa.TE, d.R, d.C, d.P, d.NV, sa.cap, sa.cnn_w ? sa.cnn_kind : -1);
+        const size_t off[12] = {L.env, L.circ, L.seg, L.best, L.obst, L.edist, L.meta, L.offs, L.ids, L.pairs, L.ecross, L.wsum};
+        for (int i = 0; i < 12; ++i) sa.lds[i] = (int)off[i];
+    }
     sa.cnn_head = h->cnn_head;
     const int blocks = (d.V + h->raster_te - 1) / h->raster_te;
     if (h->risk_model == AUV_RISK_REFERENCE)
