@@ -77,8 +77,9 @@ def test_scan_feeds_cnn_zero_copy(gold):
     sim.close()
 
 
-@pytest.mark.parametrize("mode", [_lib.LIDAR_RASTER, _lib.LIDAR_ALL_PAIRS], ids=["raster", "allpairs"])
-def test_attached_cnn_equals_separate_kernel(gold, mode):
+@pytest.mark.parametrize("mode,tile", [(_lib.LIDAR_RASTER, 0), (_lib.LIDAR_RASTER, 4), (_lib.LIDAR_ALL_PAIRS, 0)],
+                         ids=["raster", "raster-tile4", "allpairs"])
+def test_attached_cnn_equals_separate_kernel(gold, mode, tile):
     """A network attached to the batch is evaluated inside the sensing pass
     (in-kernel on the rasterising path); its output must equal the separate
     forward pass on the perception buffer bit for bit, for every network and
@@ -88,6 +89,8 @@ def test_attached_cnn_equals_separate_kernel(gold, mode):
     V = 1001
     cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=V)
     sim = make_sim(cfg, scene, lidar_mode=mode)
+    if tile:
+        sim.set_option(_lib.OPT_RASTER_TILE, tile)   # 4 envs per tile: the kernel's compile-time shape
     st = torch.cuda.current_stream()
     acts = torch.from_numpy(scenarios.random_actions(V, 2, seed=5)).cuda()
     for tag in ("shallow", "deep2", "deep"):
