@@ -19,7 +19,8 @@ both equations are met to 1e-8 m: 5,230 obstacle sightings that pin, all at
 once, the integration of the position, the body-frame bearing and the
 centre-distance form of `dist`.  K - 3.255 is an integer between 18 and 45 for
 every one of them.  Data only: rows, the vessel state before, the command, the
-two sightings and K.
+two sightings, K, and the second row's full record with its logged risk
+(data/risk_MovingObstaclesNoRules.csv).
 """
 import os
 import sys
@@ -47,6 +48,8 @@ def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     rows = [np.array(line.split(), dtype=np.float64)
             for line in open(os.path.join(ref, "data", "metadata_MovingObstaclesNoRules.csv"))]
+    risks = [np.array(line.split(), dtype=np.float64)
+             for line in open(os.path.join(ref, "data", "risk_MovingObstaclesNoRules.csv")) if line.strip()]
     cfg = importlib.import_module("gym-auv_amd.params").make_config(1, 0, 0)
 
     # segments (row A -> row A+1) with a known state at A and a known constant command
@@ -78,11 +81,13 @@ def main():
     B = advance(A.copy(), surge, steer, cfg)
     dp = B[:2] - A[:2]
 
-    out = {k: [] for k in ("row", "state", "surge", "steer", "dist_a", "bearing_a", "dist_b", "bearing_b", "offset")}
+    out = {k: [] for k in ("row", "state", "surge", "steer", "dist_a", "bearing_a", "dist_b", "bearing_b", "offset", "record_b", "risk_b")}
     for s, i in enumerate(seg_row):
         a, b = rows[i], rows[i + 1]
-        stat_a = [a[2 + 5 * o:7 + 5 * o] for o in range((len(a) - 2) // 5) if a[2 + 5 * o] == 0 and a[4 + 5 * o] == a[0]]
-        stat_b = [b[2 + 5 * o:7 + 5 * o] for o in range((len(b) - 2) // 5) if b[2 + 5 * o] == 0 and b[4 + 5 * o] == b[0]]
+        stat_a = [np.append(a[2 + 5 * o:7 + 5 * o], risks[i][o]) for o in range((len(a) - 2) // 5)
+                  if a[2 + 5 * o] == 0 and a[4 + 5 * o] == a[0]]
+        stat_b = [np.append(b[2 + 5 * o:7 + 5 * o], risks[i + 1][o]) for o in range((len(b) - 2) // 5)
+                  if b[2 + 5 * o] == 0 and b[4 + 5 * o] == b[0]]
         for ra in stat_a:
             for rb in stat_b:
                 ea = np.array([np.cos(ra[3] + A[2, s]), np.sin(ra[3] + A[2, s])])
@@ -102,13 +107,15 @@ def main():
                     out["dist_b"].append(rb[1])
                     out["bearing_b"].append(rb[3])
                     out["offset"].append(K)
+                    out["record_b"].append(rb[:5])
+                    out["risk_b"].append(rb[5])
     K = np.array(out["offset"])
     frac = np.abs((K - 3.255) - np.rint(K - 3.255))
     print(len(K), "sightings over", len(set(out["row"])), "row pairs; K - 3.255 off an integer by at most", frac.max(),
           "; radii", np.rint(K - 3.255).min(), "..", np.rint(K - 3.255).max())
     dst = os.path.join(HERE, "track_golden.npz")
     np.savez_compressed(dst, row=np.array(out["row"], dtype=np.int32), state=np.array(out["state"]).T,
-                        **{k: np.array(out[k]) for k in ("surge", "steer", "dist_a", "bearing_a", "dist_b", "bearing_b", "offset")})
+                        **{k: np.array(out[k]) for k in ("surge", "steer", "dist_a", "bearing_a", "dist_b", "bearing_b", "offset", "record_b", "risk_b")})
     print("wrote", dst)
 
 

@@ -13,7 +13,8 @@ clearance.  The clearance is 3.255 m: with it every one of the radii comes out
 as an integer (15 .. 41 m), which is what the fixture's `offset` shows.
 
 Here one env per sighting gets a circle where the first row saw it, runs the 5
-steps, and has to report the second row's dist and bearing to 1e-9 (the
+steps, and has to report the second row's dist and bearing to 1e-9, the rest
+of its record, and the risk the reference logged for it, to 1e-9 (the
 obstacle's position is itself derived from logged numbers, which costs a few
 digits; the residual of the derivation is below 1e-8 m by construction)."""
 import os
@@ -27,6 +28,7 @@ from oracle import c_oracle
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "track_golden.npz")
 TOL_DIST = 2e-8      # m, on distances of 5 .. 176 m
 TOL_BEARING = 1e-9   # rad
+TOL_RISK = 1e-9
 LOG_EVERY = 5
 
 
@@ -52,11 +54,21 @@ def scene_for(g, cfg):
             "poly_nv": np.zeros((n, 0), dtype=np.int32), "poly_heading": np.zeros((n, 0)), "path": path}
 
 
-def check(g, obst_dist, meta, collision):
+def check(g, obst_dist, meta, collision, risk=None, own=None):
     assert np.abs(obst_dist[:, 0] - g["dist_b"]).max() <= TOL_DIST
     assert np.abs(O.wrap_angle(meta[:, 0, 3] - g["bearing_b"])).max() <= TOL_BEARING
     assert np.abs(meta[:, 0, 1] - g["dist_b"]).max() <= TOL_DIST          # the logged dist column is that distance
     assert not collision.any()                                             # none of the logged sightings is a contact
+    # the rest of the second row's record as the reference logged it for a static obstacle
+    # (utils/explore_dataset.py:46: heading_ts 0, speed = speed_OS; course 0 or -pi), and its risk
+    rec = g["record_b"]
+    assert not meta[:, 0, 0].any() and not rec[:, 0].any()
+    assert np.abs(meta[:, 0, 2] - rec[:, 2]).max() <= 1e-13
+    assert np.array_equal(meta[:, 0, 4], rec[:, 4])
+    if own is not None:
+        assert np.array_equal(own[:, 0], meta[:, 0, 2])                   # speed column == speed_OS, bit for bit
+    if risk is not None:
+        assert np.abs(risk[:, 0] - g["risk_b"]).max() <= TOL_RISK
 
 
 def test_fixture_shape_and_integer_radii():
@@ -85,7 +97,7 @@ def test_numpy_oracle_tracks_the_reference_obstacles():
     act = np.stack([g["surge"], g["steer"]])
     for _ in range(LOG_EVERY):
         env.step(act)
-    check(g, env.obst_dist, env.meta, env.collision)
+    check(g, env.obst_dist, env.meta, env.collision, env.risk, env.own)
 
 
 def test_c_oracle_tracks_the_reference_obstacles():
@@ -100,5 +112,5 @@ def test_c_oracle_tracks_the_reference_obstacles():
     act = np.stack([g["surge"], g["steer"]])
     for _ in range(LOG_EVERY):
         env.step(act)
-    check(g, env.obst_dist, env.meta, env.collision)
+    check(g, env.obst_dist, env.meta, env.collision, env.risk, env.own)
     env.close()

@@ -24,7 +24,7 @@ def test_device_tracks_the_reference_obstacles(mode):
     act = np.stack([g["surge"], g["steer"]])
     for _ in range(LOG_EVERY):
         sim.step_host(act)
-    check(g, sim.read("obst_dist"), sim.read("meta"), sim.read("collision"))
+    check(g, sim.read("obst_dist"), sim.read("meta"), sim.read("collision"), sim.read("risk"), sim.read("own"))
     # and the scan sees the same obstacle: the ray nearest its bearing stops between the hull distance
     # and the tangent length
     ranges = sim.read("ranges")
