@@ -207,14 +207,17 @@ struct SenseLayout {
 __host__ __device__ inline size_t sense_cnn_bytes(int TE, int cnn_kind) {
     return cnn_kind < 0 ? 0 : ((size_t)((cnn_n_weights(cnn_kind) + 3) & ~3) + (size_t)TE * cnn_act_floats(cnn_kind)) * 4;
 }
-__host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P, int NV, int cap, int cnn_kind) {
+// packed: the narrow image of the compile-time shape (DefaultShape): edges without their stored cross
+// product, 16-bit pairs, 8-bit crossing records; 3.8 KB smaller, which is a seventh workgroup per CU.
+__host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P, int NV, int cap, int cnn_kind,
+                                                    bool packed = false) {
     SenseLayout L;
     const size_t S = (size_t)P * NV, O = (size_t)C + P;
     const size_t NP = (size_t)TE * ((size_t)C + S);
     size_t o = 0;
     L.env = o; o += (size_t)TE * 2 * 8;
     L.circ = o; o += (size_t)TE * C * 3 * 8;
-    L.seg = o; o += (size_t)TE * S * 5 * 8;
+    L.seg = o; o += (size_t)TE * S * (packed ? 4 : 5) * 8;
     const size_t act = sense_cnn_bytes(TE, cnn_kind);
     o = o < act ? act : o;
     L.best = o; o += (size_t)TE * R * 8;
@@ -228,8 +231,9 @@ __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P,
     o = (o + 15) & ~(size_t)15;
     L.meta = o; o += NP * 8;
     L.ids = o; o += (size_t)TE * R * 4;
-    L.pairs = o; o += (size_t)cap * 4;
-    L.ecross = o; o += (size_t)TE * S * 4;
+    L.pairs = o; o += (size_t)cap * (packed ? 2 : 4);
+    L.ecross = o; o += (size_t)TE * S * (packed ? 1 : 4);
+    o = (o + 3) & ~(size_t)3;
     L.wsum = o; o += 16 * 4;
     L.total = (o + 15) & ~(size_t)15;
     return L;
@@ -252,6 +256,7 @@ struct PairHit {
     unsigned long long key;
 };
 
+template <bool PACKED>
 __device__ __forceinline__ PairHit pair_test(unsigned int pr, int R, int n_circ, double range, const int2* meta,
                                              const double* env, const double* circ, const double* seg,
                                              const double* ray_dirs) {
@@ -269,8 +274,9 @@ __device__ __forceinline__ PairHit pair_test(unsigned int pr, int R, int n_circ,
     if (p < n_circ) {
         ok = circle_hit(circ[3 * p], circ[3 * p + 1], circ[3 * p + 2], dx, dy, t);
     } else {
-        const double* sg = seg + (size_t)(p - n_circ) * 5;
-        ok = edge_hit(sg[0], sg[1], sg[2], sg[3], sg[4], dx, dy, t);
+        const double* sg = seg + (size_t)(p - n_circ) * (PACKED ? 4 : 5);
+        // packed edges recompute a x e, with the operations phase 1 files it with
+        ok = edge_hit(sg[0], sg[1], sg[2], sg[3], PACKED ? sg[0] * sg[3] - sg[1] * sg[2] : sg[4], dx, dy, t);
     }
     PairHit h;
     h.ok = ok && t < range;
@@ -363,7 +369,7 @@ inline bool is_default_shape(const Dims& d, int te, int block, int cap) {
 // RISK: 0 = default risk index, 1 = the reference's index (auv_risk.hpp)
 // FIXED: the shape is DefaultShape (checked by the launcher)
 template <int RISK, bool FIXED>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k_sense(SenseArgs a) {
+__device__ __forceinline__ void sense_tile(const SenseArgs& a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int V = a.d.V;
     const int R = FIXED ? DefaultShape::R : a.d.R, C = FIXED ? DefaultShape::C : a.d.C, P = FIXED ? DefaultShape::P : a.d.P;
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
         a.lds[0], a.lds[1], a.lds[2], a.lds[3], a.lds[4], a.lds[5], a.lds[6], a.lds[7], a.lds[8], a.lds[9], a.lds[10], a.lds[11]};
     if (FIXED) {
         // constants but for the room an attached network takes in front of best[]
-        const SenseLayout T = sense_layout(TE, R, C, P, NV, cap, a.cnn_w ? a.cnn_kind : -1);
+        const SenseLayout T = sense_layout(TE, R, C, P, NV, cap, a.cnn_w ? a.cnn_kind : -1, true);
         L = {(int)T.env, (int)T.circ, (int)T.seg, (int)T.best, (int)T.obst, (int)T.edist, (int)T.meta, (int)T.offs,
              (int)T.ids, (int)T.pairs, (int)T.ecross, (int)T.wsum};
     }
@@ -393,6 +399,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
     unsigned int* ids = reinterpret_cast<unsigned int*>(lds_raw + L.ids);
     unsigned int* pairs = reinterpret_cast<unsigned int*>(lds_raw + L.pairs);
     int* ecross = reinterpret_cast<int*>(lds_raw + L.ecross);
+    // pair (primitive, ray offset) and crossing records: 16 + 16 bits and a word each, or 8 + 8 bits and a byte
+    auto pair_put = [&](int idx, unsigned int prim, unsigned int k) {
+        if (FIXED) reinterpret_cast<unsigned short*>(pairs)[idx] = (unsigned short)((prim << 8) | k);
+        else pairs[idx] = (prim << 16) | k;
+    };
+    auto pair_get = [&](int idx) -> unsigned int {
+        if (!FIXED) return pairs[idx];
+        const unsigned int v = reinterpret_cast<const unsigned short*>(pairs)[idx];
+        return ((v >> 8) << 16) | (v & 0xffu);
+    };
+    auto ecross_put = [&](int idx, int v) {
+        if (FIXED) reinterpret_cast<unsigned char*>(ecross)[idx] = (unsigned char)v;
+        else ecross[idx] = v;
+    };
+    auto ecross_get = [&](int idx) -> int {
+        return FIXED ? (int)reinterpret_cast<const unsigned char*>(ecross)[idx] : ecross[idx];
+    };
     int* wsum = reinterpret_cast<int*>(lds_raw + L.wsum);  // [0..7] wave sums of the fallback scan, [14],[15] pair counters
     const int e0 = blockIdx.x * TE;
     const int ne = min(TE, V - e0);
@@ -487,7 +510,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
             const int base = atomicAdd(&wsum[14], iv.y);
             const int room = min(iv.y, cap - base);  // writes stay inside the list even when it overflows
             AUV_CHECK(base >= 0 && (room <= 0 || base + room <= cap));
-            for (int k = 0; k < room; ++k) pairs[base + k] = ((unsigned int)i << 16) | (unsigned int)k;
+            for (int k = 0; k < room; ++k) pair_put(base + k, (unsigned int)i, (unsigned int)k);
         }
     }
     for (int i = tid; i < ne * S; i += nthr) {
@@ -579,14 +602,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
                 }
             }
         }
-        double* sg = seg + (size_t)i * 5;
+        double* sg = seg + (size_t)i * (FIXED ? 4 : 5);
         sg[0] = ax;
         sg[1] = ay;
         sg[2] = ex;
         sg[3] = ey;
-        sg[4] = nt;
+        if (!FIXED) sg[4] = nt;
         edist[i] = dd;
-        ecross[i] = k == 0 ? (cross | (nv << 1)) : cross;  // edge 0 also carries the vertex count
+        ecross_put(i, k == 0 ? (cross | (nv << 1)) : cross);  // edge 0 also carries the vertex count
         AUV_CHECK(i >= 0 && i < TE * S && el >= 0 && el < ne && q >= 0 && q < P && iv.x >= 0 && iv.x < R && iv.y <= R);
         meta[n_circ + i] = pack_meta(iv.x, iv.y, el, C + q);
         if (iv.y > 0) {
@@ -596,7 +619,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
             AUV_CHECK(top <= cap && (room <= 0 || top - room >= 0));
 #pragma nounroll  // a handful of rays per edge: the unrolled form only adds set-up
             for (int kk = 0; kk < room; ++kk)
-                pairs[top - 1 - kk] = ((unsigned int)(n_circ + i) << 16) | (unsigned int)kk;
+                pair_put(top - 1 - kk, (unsigned int)(n_circ + i), (unsigned int)kk);
         }
     }
     if (tid < ne) {
@@ -630,14 +653,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
         auto hull_distance = [&](const double* ob, int el, int o) -> double {
             if (o < C) return ob[OB_DIST * ob_n];
             const int s0 = el * S + (o - C) * NV;
-            const int nv = ecross[s0] >> 1;
+            const int nv = ecross_get(s0) >> 1;
             AUV_CHECK(s0 >= 0 && s0 + NV <= TE * S && nv >= 0 && nv <= NV);
             double dmin2 = __builtin_inf();
             int par = 0;
             for (int k = 0; k < nv; ++k) {
                 const double d2 = edist[s0 + k];
                 dmin2 = d2 < dmin2 ? d2 : dmin2;
-                par ^= ecross[s0 + k] & 1;
+                par ^= ecross_get(s0 + k) & 1;
             }
             const double dmin = __builtin_sqrt(dmin2);
             return nv > 0 ? (par ? -dmin : dmin) - a.vessel_radius : __builtin_inf();
@@ -647,7 +670,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
         // across its heading), a circle's its radius, i.e. the hull distance
         auto ref_distance = [&](const double* ob, int el, int o, double mx, double my) -> double {
             if (o < C) return ob[OB_DIST * ob_n];
-            const int nv = ecross[el * S + (o - C) * NV] >> 1;
+            const int nv = ecross_get(el * S + (o - C) * NV) >> 1;
             const double beam = pobs[PB_HEADING * pb_n + (el * P + (o - C))];
             return nv > 0 ? (__builtin_sqrt(mx * mx + my * my) - beam) - a.vessel_radius : __builtin_inf();
         };
@@ -767,14 +790,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
             const int w = tid + j * nthr;
             if (w < total) {
                 AUV_CHECK((w < n_cp ? w : cap - n_ep + (w - n_cp)) >= 0 && (w < n_cp ? w : cap - n_ep + (w - n_cp)) < cap);
-                kept[j] = pair_test(pairs[w < n_cp ? w : cap - n_ep + (w - n_cp)], R, n_circ, range, meta, env, circ,
+                kept[j] = pair_test<FIXED>(pair_get(w < n_cp ? w : cap - n_ep + (w - n_cp)), R, n_circ, range, meta, env, circ,
                                     seg, a.ray_dirs);
                 AUV_CHECK(!kept[j].ok || (kept[j].slot >= 0 && kept[j].slot < ne * R && (int)kept[j].oid < O));
                 if (kept[j].ok) atomicMin(&best[kept[j].slot], kept[j].key);
             }
         }
         for (int w = tid + kKeep * nthr; w < total; w += nthr) {
-            const PairHit h = pair_test(pairs[w < n_cp ? w : cap - n_ep + (w - n_cp)], R, n_circ, range, meta, env,
+            const PairHit h = pair_test<FIXED>(pair_get(w < n_cp ? w : cap - n_ep + (w - n_cp)), R, n_circ, range, meta, env,
                                         circ, seg, a.ray_dirs);
             if (h.ok) atomicMin(&best[h.slot], h.key);
         }
@@ -785,7 +808,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
         for (int j = 0; j < kKeep; ++j)
             if (kept[j].ok && best[kept[j].slot] == kept[j].key) atomicMin(&ids[kept[j].slot], kept[j].oid);
         for (int w = tid + kKeep * nthr; w < total; w += nthr) {
-            const PairHit h = pair_test(pairs[w < n_cp ? w : cap - n_ep + (w - n_cp)], R, n_circ, range, meta, env,
+            const PairHit h = pair_test<FIXED>(pair_get(w < n_cp ? w : cap - n_ep + (w - n_cp)), R, n_circ, range, meta, env,
                                         circ, seg, a.ray_dirs);
             if (h.ok && best[h.slot] == h.key) atomicMin(&ids[h.slot], h.oid);
         }
@@ -823,11 +846,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
                     const int o = offs[p];
                     const int lo = max(o, w0), hi = min(o + meta_count(meta[p]), w0 + cap);
                     AUV_CHECK(lo >= hi || (lo - w0 >= 0 && hi - w0 <= cap));
-                    for (int w = lo; w < hi; ++w) pairs[w - w0] = ((unsigned int)p << 16) | (unsigned int)(w - o);
+                    for (int w = lo; w < hi; ++w) pair_put(w - w0, (unsigned int)p, (unsigned int)(w - o));
                 }
                 __syncthreads();
                 for (int w = tid; w < n_pairs; w += nthr) {
-                    const PairHit h = pair_test(pairs[w], R, n_circ, range, meta, env, circ, seg, a.ray_dirs);
+                    const PairHit h = pair_test<FIXED>(pair_get(w), R, n_circ, range, meta, env, circ, seg, a.ray_dirs);
                     if (h.ok) {
                         AUV_CHECK(h.slot >= 0 && h.slot < ne * R && (int)h.oid < O);
                         if (pass == 0) atomicMin(&best[h.slot], h.key);
@@ -867,6 +890,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k
                                  a.cnn_head, tid, nthr);
     }
     AUV_STAMP(9);
+}
+
+// generic shape
+template <int RISK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k_sense(SenseArgs a) {
+    sense_tile<RISK, false>(a);
+}
+
+// DefaultShape.  A CU admits floor(800 / (scalar registers rounded up to 16, + 16)) workgroups of 256
+// threads: held to 96 scalar registers the kernel gets 7 per CU instead of 6, and its narrow LDS image
+// (23.0 KB) lets them in.
+template <int RISK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_sense_default(SenseArgs a) {
+    sense_tile<RISK, true>(a);
 }
 
 }  // namespace auv

@@ -361,12 +361,14 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.cnn_head = h->cnn_head;
     const int blocks = (d.V + h->raster_te - 1) / h->raster_te;
     const bool fixed = is_default_shape(d, h->raster_te, h->sense_block, h->raster_cap);
+    // the compile-time shape has a narrower LDS image
+    const size_t lds_fixed = sense_layout(sa.TE, d.R, d.C, d.P, d.NV, sa.cap, sa.cnn_w ? sa.cnn_kind : -1, true).total;
     if (h->risk_model == AUV_RISK_REFERENCE) {
-        if (fixed) hipLaunchKernelGGL((k_sense<1, true>), dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
-        else hipLaunchKernelGGL((k_sense<1, false>), dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
+        if (fixed) hipLaunchKernelGGL(k_sense_default<1>, dim3(blocks), dim3(h->sense_block), lds_fixed, st, sa);
+        else hipLaunchKernelGGL(k_sense<1>, dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
     } else {
-        if (fixed) hipLaunchKernelGGL((k_sense<0, true>), dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
-        else hipLaunchKernelGGL((k_sense<0, false>), dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
+        if (fixed) hipLaunchKernelGGL(k_sense_default<0>, dim3(blocks), dim3(h->sense_block), lds_fixed, st, sa);
+        else hipLaunchKernelGGL(k_sense<0>, dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
     }
     HIP_TRY(h, hipGetLastError());
     if (h->cnn_w && !cnn_inside) {
@@ -561,9 +563,9 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     d.O = d.C + d.P;
     choose_geometry(h);
     // dynamic LDS beyond the 64 KiB default window has to be granted per kernel
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sense<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sense<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsMax) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_sense<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_sense<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsMax) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_lidar), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsMax) != hipSuccess) {
