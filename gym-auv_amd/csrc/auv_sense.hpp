@@ -157,6 +157,7 @@ struct SenseArgs {
     int cap;      // pair-list slots per round
     int is_step;  // 1: advance obstacles, finish the reward; 0: after reset / plain sense
     int with_meta;  // 0: bearing, course and risk of the obstacles are not refreshed by this pass
+    int refresh_heading;  // 0: the heading_ts column (a constant of the scene) is rewritten only for restarting envs
     const double* state;
     const double* envrec;
     double* circles;    // [V,C,5]  positions updated in place when is_step
@@ -738,7 +739,8 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a) {
                         const double psi = a.state[2 * (size_t)V + e];
                         const double ang = wrap_angle(atan2_det(task == 1 ? my : rvy, task == 1 ? mx : rvx) - psi);
                         m[2 + task] = ang;
-                        if (RISK == 1 && task == 1) m[0] = (ov[0] == 0.0 && ov[1] == 0.0) ? 0.0 : atan2_det(ov[1], ov[0]);
+                        if (RISK == 1 && task == 1 && (a.refresh_heading || a.envrec[(size_t)e * ER_COUNT + ER_RESET] != 0.0))
+                            m[0] = (ov[0] == 0.0 && ov[1] == 0.0) ? 0.0 : atan2_det(ov[1], ov[0]);
                     }
                 }
                 if (task == 0 && lanes_per_env) {

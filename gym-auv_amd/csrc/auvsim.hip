@@ -77,6 +77,7 @@ struct auv_sim {
     int block_want = 0;   // threads per workgroup asked for (0 = automatic)
     int auto_reset = 0;   // done envs restart inside the next step
     int regenerate = 0;   // ... with a newly generated scene
+    bool heading_stale = true;  // the heading_ts column has to be rewritten for every env by the next sensing pass
     int meta_every = 1;   // steps between refreshes of bearing / course / risk (0: only outside steps)
     int risk_model = AUV_RISK_REFERENCE;
     long long step_count = 0;
@@ -318,6 +319,10 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.is_step = do_step;
     if (do_step) h->step_count++;
     sa.with_meta = !do_step || (h->meta_every > 0 && h->step_count % h->meta_every == 0);
+    // an obstacle's heading_ts is a constant of the scene: rewritten outside steps, after the scene or the risk
+    // index changed, and (in the kernel) for envs that restart in this step
+    sa.refresh_heading = !do_step || h->heading_stale || h->meta_every != 1;
+    if (sa.with_meta) h->heading_stale = false;
     sa.state = bp<double>(h, AUV_BUF_STATE);
     sa.envrec = h->envrec;
     sa.circles = bp<double>(h, AUV_BUF_CIRCLES);
@@ -710,6 +715,7 @@ int auv_set_scene(auv_handle h, int32_t env_begin, int32_t env_count, const doub
     if (path) HIP_TRY(h, hipMemcpy(h->path + b * 6, path, n * 6 * sizeof(double), hipMemcpyHostToDevice));
     // the scene counts as complete once one call has covered all envs, or the
     // calls so far were a front-to-back sweep ending at V
+    h->heading_stale = true;
     if (env_begin == 0 && env_count == d.V) h->have_scene = true;
     else if (env_begin + env_count == d.V) h->have_scene = true;
     return AUV_OK;
@@ -727,6 +733,7 @@ int auv_generate_scene(auv_handle h, uint64_t seed, const auv_scene_params* para
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = pick(h, stream);
     h->gen_seed = seed;
+    h->heading_stale = true;
     h->gen_params = p;
     HIP_TRY(h, hipMemsetAsync(bp<int32_t>(h, AUV_BUF_EPISODE), 0, (size_t)d.V * sizeof(int32_t), st));
     int rc = launch_scenegen(h, st, nullptr);
@@ -931,6 +938,7 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
             if (value != AUV_RISK_CPA && value != AUV_RISK_REFERENCE)
                 return fail(h, AUV_ERR_ARG, "auv_set_option: AUV_OPT_RISK_MODEL takes AUV_RISK_REFERENCE or AUV_RISK_CPA");
             h->risk_model = value;
+            h->heading_stale = true;
             return AUV_OK;
         case AUV_OPT_REGENERATE:
             if (value != 0 && value != 1) return fail(h, AUV_ERR_ARG, "auv_set_option: AUV_OPT_REGENERATE takes 0 or 1");

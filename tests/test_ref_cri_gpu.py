@@ -113,6 +113,13 @@ def test_simulation_with_the_reference_index(mode):
     sim.step_host(acts[0])
     env.step(acts[0])
     assert_all_equal(sim, env, "after switching back")
+    # and to the reference's index again: every column of the records follows, the scene-constant ones included
+    sim.set_option(_lib.OPT_RISK_MODEL, _lib.RISK_REFERENCE)
+    env.cfg = dict(env.cfg, risk_model=1)
+    for k in (1, 2):
+        sim.step_host(acts[k])
+        env.step(acts[k])
+        assert_all_equal(sim, env, f"reference index again, step {k}")
     sim.close()
 
 
