@@ -33,15 +33,18 @@ HBM_PEAK_GBS = 8000.0
 FLOP_CIRCLE, FLOP_SEGMENT = 16, 18   # per ray-primitive test (add/mul/cmp/div/sqrt = 1)
 
 
-def sense_bytes_per_env(R, C, P, NV):
+def sense_bytes_per_env(R, C, P, NV, meta_fields=5):
     """Algorithmic HBM bytes of one k_sense launch per env-step: scene and
-    vessel record in, advanced positions back, every output out (no re-reads)."""
+    vessel record in, advanced positions back, every output out (no re-reads).
+    meta_fields: columns of a metadata record written per step (with the
+    reference's index the heading column is a constant of the scene and is
+    not rewritten: 4)."""
     O = C + P
     scene_in = C * 40 + P * (48 + NV * 16 + 4 + 8)
     vessel_in = 48 + 64 + 2
     pos_out = O * 16
     lidar_out = R * 16
-    encounter_out = O * (8 + 8 + 40) + (1 + 1 + 8 + 4 + 8)
+    encounter_out = O * (8 + 8 + 8 * meta_fields) + (1 + 1 + 8 + 4 + 8)
     return scene_in + vessel_in + pos_out + lidar_out + encounter_out
 
 
@@ -336,7 +339,8 @@ def main():
         if args.risk_model != "reference":
             tkey += "/" + args.risk_model     # the committed counters are those of the default index
         if fused:
-            nbytes = float(sense_bytes_per_env(R, C, P, NV) + 4 * cnn_dim) * V
+            meta_fields = 4 if (args.risk_model == "reference" and args.meta_every == 1) else 5
+            nbytes = float(sense_bytes_per_env(R, C, P, NV, meta_fields) + 4 * cnn_dim) * V
             gbs = nbytes / sense_s / 1e9
             out["roofline"] = {
                 "kernel": "k_sense", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
