@@ -61,6 +61,7 @@ struct SceneGenArgs {
     int32_t* poly_nv;
     double* poly_heading;
     double* poly_beam;
+    double* poly_rot;           // [V,P,NV,2]
     double* path;  // [V,6]
     double* init;  // [6,V]
     double extent, r_lo, r_hi, w_lo, w_hi, s_lo, s_hi, clearance, path_length;
@@ -146,6 +147,11 @@ __global__ __launch_bounds__(256) void k_scenegen(SceneGenArgs a) {
         a.poly_nv[ep_i] = 5;
         a.poly_heading[ep_i] = h;
         a.poly_beam[ep_i] = hw - (-hw);
+        double* rt = a.poly_rot + ep_i * NV * 2;
+        for (int k = 0; k < NV; ++k) {
+            rt[2 * k] = sc.c * v[2 * k] - sc.s * v[2 * k + 1];
+            rt[2 * k + 1] = sc.s * v[2 * k] + sc.c * v[2 * k + 1];
+        }
     }
 }
 

@@ -166,6 +166,7 @@ struct SenseArgs {
     const int32_t* poly_nv;
     const double* poly_heading;
     const double* poly_beam;  // [V,P]
+    const double* poly_rot;   // [V,P,NV,2] R(heading) * body-frame vertex
     const double* ray_dirs;
     double* ranges;
     int32_t* hit;
@@ -524,12 +525,12 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a) {
         const int nv = a.poly_nv[ep];
         const double* p = a.poly_pose + ep * 6;
         // every vertex slot exists in memory, so the loads need not wait for nv
-        const double* vb = a.poly_verts + ep * NV * 2;
+        const double* vb = a.poly_rot + ep * NV * 2;  // already turned to the ship's heading
         const int k1c = (k + 1 < NV) ? k + 1 : 0;
         const double vkx = vb[2 * k], vky = vb[2 * k + 1];
         const double v1x = vb[2 * k1c], v1y = vb[2 * k1c + 1], v0x = vb[0], v0y = vb[1];
         double X = p[0], Y = p[1];
-        const double ch = p[2], sh = p[3], pvx = p[4], pvy = p[5];
+        const double pvx = p[4], pvy = p[5];
         if (a.is_step && a.envrec[(size_t)e * ER_COUNT + ER_RESET] == 0.0) {
             X = X + pvx * a.dt;
             Y = Y + pvy * a.dt;
@@ -556,10 +557,10 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a) {
         if (k < nv) {
             const bool wrap = k + 1 >= nv;  // the last edge closes on vertex 0
             const double bx = wrap ? v0x : v1x, by_ = wrap ? v0y : v1y;
-            const double Ax = X + (ch * vkx - sh * vky);
-            const double Ay = Y + (sh * vkx + ch * vky);
-            const double Bx = X + (ch * bx - sh * by_);
-            const double By = Y + (sh * bx + ch * by_);
+            const double Ax = X + vkx;
+            const double Ay = Y + vky;
+            const double Bx = X + bx;
+            const double By = Y + by_;
             ax = Ax - px;
             ay = Ay - py;
             const double by = By - py;

@@ -59,6 +59,7 @@ struct auv_sim {
     double* poly_verts = nullptr;
     int32_t* poly_nv = nullptr;
     double* poly_heading = nullptr;
+    double* poly_rot = nullptr;   // [V,P,NV,2] vertices turned to the ship's heading (world-frame offsets from its centre; a scene constant)
     double* poly_beam = nullptr;  // [V,P] extent of the body-frame vertices across the heading (a scene constant)
     double* path = nullptr;
     double* ray_dirs = nullptr;
@@ -227,6 +228,7 @@ int launch_scenegen(auv_sim* h, hipStream_t st, const uint8_t* only_done) {
     ga.poly_nv = h->poly_nv;
     ga.poly_heading = h->poly_heading;
     ga.poly_beam = h->poly_beam;
+    ga.poly_rot = h->poly_rot;
     ga.path = h->path;
     ga.init = h->init_stage;
     const auv_scene_params& p = h->gen_params;
@@ -331,6 +333,7 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.poly_nv = h->poly_nv;
     sa.poly_heading = h->poly_heading;
     sa.poly_beam = h->poly_beam;
+    sa.poly_rot = h->poly_rot;
     sa.ray_dirs = h->ray_dirs;
     sa.ranges = bp<double>(h, AUV_BUF_RANGES);
     sa.hit = bp<int32_t>(h, AUV_BUF_HIT);
@@ -612,6 +615,7 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     chk(alloc_buf(h, AUV_BUF_EPISODE, AUV_I32, {V}));
     chk(alloc_buf(h, AUV_BUF_CNN_OUT, AUV_F32, {V, 12}));  // widest head; the shape follows the attached network
     chk(alloc_raw(h, &h->poly_verts, (size_t)V * P * NV * 2));
+    chk(alloc_raw(h, &h->poly_rot, (size_t)V * P * NV * 2));
     chk(alloc_raw(h, &h->poly_nv, (size_t)V * P));
     chk(alloc_raw(h, &h->poly_heading, (size_t)V * P));
     chk(alloc_raw(h, &h->poly_beam, (size_t)V * P));
@@ -649,7 +653,7 @@ void auv_destroy(auv_handle h) {
     for (auto& ev : h->events) (void)hipEventDestroy(ev);
     for (auto& b : h->buf)
         if (b.ptr) (void)hipFree(b.ptr);
-    void* raw[] = {h->poly_verts, h->poly_nv, h->poly_heading, h->poly_beam, h->path, h->ray_dirs, h->init_stage, h->mask_stage,
+    void* raw[] = {h->poly_verts, h->poly_rot, h->poly_nv, h->poly_heading, h->poly_beam, h->path, h->ray_dirs, h->init_stage, h->mask_stage,
                    h->circles0, h->poly_pose0, h->envrec, h->cnn_w};
     for (void* p : raw)
         if (p) (void)hipFree(p);
@@ -711,6 +715,17 @@ int auv_set_scene(auv_handle h, int32_t env_begin, int32_t env_count, const doub
             if (poly_nv[i] > 0) beam[i] = hi - lo;
         }
         HIP_TRY(h, hipMemcpy(h->poly_beam + b * d.P, beam.data(), n * d.P * sizeof(double), hipMemcpyHostToDevice));
+        // every vertex slot turned to its ship's heading: R(h) * body, the offsets the sensing kernel adds to the centre
+        std::vector<double> rot(n * d.P * d.NV * 2);
+        for (size_t i = 0; i < n * d.P; ++i) {
+            const double ch = poly_pose[i * 6 + 2], sh = poly_pose[i * 6 + 3];
+            for (int k = 0; k < d.NV; ++k) {
+                const double vx = poly_verts[(i * d.NV + k) * 2], vy = poly_verts[(i * d.NV + k) * 2 + 1];
+                rot[(i * d.NV + k) * 2] = ch * vx - sh * vy;
+                rot[(i * d.NV + k) * 2 + 1] = sh * vx + ch * vy;
+            }
+        }
+        HIP_TRY(h, hipMemcpy(h->poly_rot + b * d.P * d.NV * 2, rot.data(), rot.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     if (path) HIP_TRY(h, hipMemcpy(h->path + b * 6, path, n * 6 * sizeof(double), hipMemcpyHostToDevice));
     // the scene counts as complete once one call has covered all envs, or the
