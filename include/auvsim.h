@@ -97,8 +97,10 @@ typedef enum auv_buffer {
     AUV_BUF_MIN_IDX = 15,    /* i32 [V] */
     AUV_BUF_ALONG = 16,      /* f64 [V]   along-track position on the path */
     AUV_BUF_T_STEP = 17,     /* i32 [V] */
-    AUV_BUF_CIRCLES = 18,    /* f64 [V,C,5] cx,cy,rad,vx,vy */
-    AUV_BUF_POLY_POSE = 19,  /* f64 [V,P,6] X,Y,cos h,sin h,vx,vy */
+    AUV_BUF_CIRCLES = 18,    /* f64 [V,C,5] cx,cy,rad,vx,vy.  The live obstacle records: read them freely, but change a
+                                scene through auv_set_scene / auv_generate_scene only: the library keeps per-scene
+                                constants derived from them (headings, beams, turned vertices, the initial poses) */
+    AUV_BUF_POLY_POSE = 19,  /* f64 [V,P,6] X,Y,cos h,sin h,vx,vy (same rule) */
     AUV_BUF_REWARD = 20,     /* f64 [V]   reward of the last step (0 after reset) */
     AUV_BUF_CNN_OUT = 21,    /* f32 [V,out_dim] output of the attached network (auv_attach_cnn); zeros, out_dim 12, before */
     AUV_BUF_EPISODE = 22,    /* i32 [V]   in-step restarts of the env so far (= its episode number for the generator) */
