@@ -19,6 +19,7 @@
 #include "auv_cnn.hpp"
 #include "auv_scenegen.hpp"
 #include "auv_format.hpp"
+#include "auv_stats.hpp"
 
 using namespace auv;
 
@@ -68,6 +69,7 @@ struct auv_sim {
     double* poly_pose0 = nullptr;
     double* envrec = nullptr;      // [V,8] k_vessel -> k_sense hand-off
     uint8_t* mask_stage = nullptr;
+    double* stats_ws = nullptr;    // [stats_blocks(V), kStatsFields] records of k_stats_partial
     bool have_rays = false, have_scene = false, have_state = false;
     // launch geometry
     int lidar_te = 1, lidar_block = 256, enc_eb = 1;
@@ -459,6 +461,29 @@ int launch_sense(auv_sim* h, hipStream_t st, hipEvent_t* ev, int is_step) {
     return AUV_OK;
 }
 
+// the two launches of the statistics reduction, with `records` as the workspace
+int launch_stats(auv_sim* h, double* records, double* out, int accumulate, hipStream_t st) {
+    const Dims& d = h->d;
+    StatsArgs sa;
+    sa.V = d.V;
+    sa.R = d.R;
+    sa.O = d.O;
+    sa.done = bp<uint8_t>(h, AUV_BUF_DONE);
+    sa.collision = bp<uint8_t>(h, AUV_BUF_COLLISION);
+    sa.reached_goal = bp<uint8_t>(h, AUV_BUF_REACHED_GOAL);
+    sa.truncated = bp<uint8_t>(h, AUV_BUF_TRUNCATED);
+    sa.reward = bp<double>(h, AUV_BUF_REWARD);
+    sa.ranges = bp<double>(h, AUV_BUF_RANGES);
+    sa.risk = bp<double>(h, AUV_BUF_RISK);
+    sa.records = records;
+    const int blocks = stats_blocks(d.V);
+    hipLaunchKernelGGL(k_stats_partial, dim3(blocks), dim3(kStatsThreads), 0, st, sa);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(kStatsThreads), 0, st, records, blocks, out, accumulate);
+    HIP_TRY(h, hipGetLastError());
+    return AUV_OK;
+}
+
 int drain_profile(auv_sim* h) {
     if (h->prof_pending == 0) return AUV_OK;
     hipEvent_t* last = &h->events[(size_t)(h->prof_pending - 1) * 4];
@@ -626,6 +651,7 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     chk(alloc_raw(h, &h->poly_pose0, (size_t)V * P * 6));
     chk(alloc_raw(h, &h->envrec, (size_t)V * ER_COUNT));
     chk(alloc_raw(h, &h->mask_stage, (size_t)V));
+    chk(alloc_raw(h, &h->stats_ws, (size_t)stats_blocks(d.V) * kStatsFields));
     if (rc == AUV_OK && hipDeviceSynchronize() != hipSuccess) rc = AUV_ERR_DEVICE;
     if (rc != AUV_OK) {
         g_create_error = "auv_create: " + h->err;
@@ -654,7 +680,7 @@ void auv_destroy(auv_handle h) {
     for (auto& b : h->buf)
         if (b.ptr) (void)hipFree(b.ptr);
     void* raw[] = {h->poly_verts, h->poly_rot, h->poly_nv, h->poly_heading, h->poly_beam, h->path, h->ray_dirs, h->init_stage, h->mask_stage,
-                   h->circles0, h->poly_pose0, h->envrec, h->cnn_w};
+                   h->circles0, h->poly_pose0, h->envrec, h->cnn_w, h->stats_ws};
     for (void* p : raw)
         if (p) (void)hipFree(p);
     delete h;
@@ -1017,6 +1043,17 @@ int auv_debug_set_stamps(void* p) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof p) == hipSuccess ? AUV_OK : AUV_ERR_DEVICE;
 }
 #endif
+
+// ---- episode statistics -------------------------------------------------------
+
+int auv_episode_stats(auv_handle h, double* out, int32_t accumulate, void* stream) {
+    if (!h) return AUV_ERR_ARG;
+    if (!out) return fail(h, AUV_ERR_ARG, "auv_episode_stats: out is NULL");
+    int rc = ready_to_run(h, true);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return launch_stats(h, h->stats_ws, out, accumulate, pick(h, stream));
+}
 
 // ---- dataset text rows (host only) ------------------------------------------
 

@@ -52,6 +52,11 @@ class EpisodeStats:
                  risk.amax(dim=-1).sum(dtype=f64) if risk is not None else self.vec.new_zeros(())]
         self.vec += torch.stack(parts)
 
+    def update_from_sim(self, sim, stream=None):
+        """The same accumulation, reduced by the library itself (`auv_episode_stats`:
+        two small launches, nothing allocated) instead of ten torch reductions."""
+        sim.episode_stats(self.vec, accumulate=True, stream=stream)
+
     def reduce(self, group=None) -> dict:
         return reduce_episode_stats(self.vec, group)
 

@@ -236,6 +236,22 @@ class AuvSim:
                                             C.c_void_p(out.data_ptr()), _stream_handle(stream)))
         return out
 
+    def episode_stats(self, out, accumulate: bool = False, stream=None):
+        """Reduce the batch's current outputs into `out`, a float64 CUDA tensor of
+        `_lib.STATS_FIELDS` elements (order: `dist.STAT_FIELDS`), on the device;
+        accumulate=True adds to it."""
+        import torch
+        if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float64
+                and out.is_contiguous() and out.numel() == _lib.STATS_FIELDS):
+            raise TypeError(f"episode_stats takes a contiguous float64 CUDA tensor of {_lib.STATS_FIELDS} elements")
+        if out.device.index != self.device:
+            raise ValueError(f"episode_stats: tensor on cuda:{out.device.index}, simulation on cuda:{self.device}")
+        if stream is None:
+            stream = torch.cuda.current_stream(out.device)
+        self._check(self._lib.auv_episode_stats(self._h, C.c_void_p(out.data_ptr()), 1 if accumulate else 0,
+                                                _stream_handle(stream)))
+        return out
+
     # -- profiling ----------------------------------------------------------
     def profile(self, on: bool):
         self._check(self._lib.auv_profile_enable(self._h, 1 if on else 0))

@@ -248,6 +248,22 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value);
 int auv_profile_enable(auv_handle h, int32_t on);
 int auv_profile_read(auv_handle h, double ms[3], int64_t* n_steps);
 
+/* ---- episode statistics, reduced on the device ------------------------------
+ * out (DEVICE f64 [AUV_STATS_FIELDS]) = over the batch's current outputs:
+ * {number of envs, sum of AUV_BUF_DONE, of AUV_BUF_COLLISION, of
+ * AUV_BUF_REACHED_GOAL, of AUV_BUF_TRUNCATED, of AUV_BUF_REWARD, sum over envs of
+ * the nearest LiDAR return (min over the rays of AUV_BUF_RANGES), sum over envs
+ * of the largest obstacle risk (max over AUV_BUF_RISK, 0 without obstacles)}.
+ * accumulate != 0 adds to `out` instead of overwriting it, so a rollout's
+ * statistics build up on the device and cross to the host (or into the
+ * all-reduce of a multi-GPU job) once.  Two small launches on `stream`, a
+ * workspace owned by the handle, sums folded in a fixed order (the same bits
+ * on every call).  The task-level numbers the reference reports per agent
+ * (results_RL/DRL_performance.txt:1-10: progress, collision avoidance, time) are
+ * ratios of these sums. */
+#define AUV_STATS_FIELDS 8
+int auv_episode_stats(auv_handle h, double* out, int32_t accumulate, void* stream);
+
 /* ---- dataset text rows (host only, no GPU involved) -------------------------
  * Formats n_rows ragged rows of doubles as the reference's dataset files do
  * (numpy.savetxt defaults: "%.18e", single spaces, "\n"; the files read by
