@@ -40,6 +40,7 @@ OPT_RISK_MODEL = 6
 LIDAR_RASTER, LIDAR_ALL_PAIRS = 0, 1
 RISK_CPA, RISK_REFERENCE = 0, 1
 STATS_FIELDS = 8
+STATS_MAX_ENVS = 1048576
 
 # CNN consumers
 CNN_SHALLOW, CNN_2DEEP, CNN_DEEP = 0, 1, 2
@@ -53,7 +54,7 @@ EXPORTS = (
     "auv_profile_enable", "auv_cnn_n_weights", "auv_cnn_out_dim", "auv_cnn_create", "auv_cnn_destroy",
     "auv_cnn_forward", "auv_cnn_last_error", "auv_format_rows",
     "auv_profile_read", "auv_attach_cnn", "auv_generate_scene", "auv_host_alloc", "auv_host_free",
-    "auv_risk_rows", "auv_episode_stats",
+    "auv_risk_rows", "auv_episode_stats", "auv_episode_stats_static",
 )
 
 
@@ -163,5 +164,7 @@ def load():
     lib.auv_risk_rows.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.auv_episode_stats.restype = C.c_int
     lib.auv_episode_stats.argtypes = [vp, vp, i32, vp]
+    lib.auv_episode_stats_static.restype = C.c_int
+    lib.auv_episode_stats_static.argtypes = [vp, vp, i32, vp]
     _lib = lib
     return lib

@@ -10,6 +10,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,31 @@ size_t dtype_size(int32_t dt) {
 constexpr size_t kLdsMax = 160u * 1024u;  // LDS of one gfx950 CU; a workgroup may claim all of it
 constexpr int kProfRing = 256;  // steps whose events are kept before a forced drain
 
+}  // namespace
+
+// Records of k_stats_partial for auv_episode_stats_static: a fixed array in the device image instead of an
+// allocation.  In host code this name is only a handle for hipGetSymbolAddress; kernels and copies get the
+// per-device address kept in g_scratch_ptr.
+constexpr int kScratchRecords = AUV_STATS_MAX_ENVS / auv::kStatsEnvs;
+static __device__ __align__(256) double scratch[(size_t)kScratchRecords * auv::kStatsFields];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+double* g_scratch_ptr[kMaxDevices] = {};  // address of `scratch` on each device, resolved once per device
+
+// Resolves the address of `scratch` on `device`, which must be the current device.
+hipError_t resolve_scratch(int device) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    double* p = nullptr;
+    hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = p;
+    return hipSuccess;
+}
 }  // namespace
 
 struct auv_sim {
@@ -584,6 +610,10 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     e = hipSetDevice(device);
     if (e != hipSuccess) return fail(nullptr, AUV_ERR_DEVICE, "hipSetDevice: %s", hipGetErrorString(e));
 
+    e = resolve_scratch(device);  // once per device, here, so that auv_episode_stats_static never sets anything up
+    if (e != hipSuccess)
+        return fail(nullptr, AUV_ERR_DEVICE, "auv_create: cannot resolve the statistics scratch array on device %d: %s",
+                    device, hipGetErrorString(e));
     auv_sim* h = new auv_sim();
     h->cfg = *cfg;
     h->device = device;
@@ -1053,6 +1083,20 @@ int auv_episode_stats(auv_handle h, double* out, int32_t accumulate, void* strea
     if (rc) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     return launch_stats(h, h->stats_ws, out, accumulate, pick(h, stream));
+}
+
+int auv_episode_stats_static(auv_handle h, double* out, int32_t accumulate, void* stream) {
+    if (!h) return AUV_ERR_ARG;
+    if (!out) return fail(h, AUV_ERR_ARG, "auv_episode_stats_static: out is NULL");
+    if (h->d.V > AUV_STATS_MAX_ENVS)
+        return fail(h, AUV_ERR_ARG, "auv_episode_stats_static: batch of %d envs exceeds the fixed scratch array (%d envs); "
+                    "use auv_episode_stats", h->d.V, AUV_STATS_MAX_ENVS);
+    int rc = ready_to_run(h, true);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    double* records = g_scratch_ptr[h->device];  // resolved by auv_create on this device
+    if (!records) return fail(h, AUV_ERR_STATE, "auv_episode_stats_static: scratch array of device %d unresolved", h->device);
+    return launch_stats(h, records, out, accumulate, pick(h, stream));
 }
 
 // ---- dataset text rows (host only) ------------------------------------------

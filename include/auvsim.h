@@ -264,6 +264,20 @@ int auv_profile_read(auv_handle h, double ms[3], int64_t* n_steps);
 #define AUV_STATS_FIELDS 8
 int auv_episode_stats(auv_handle h, double* out, int32_t accumulate, void* stream);
 
+/* auv_episode_stats for callers that cannot allocate: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no
+ * counterpart in the reference.  Same arguments, same kernels, same bits in
+ * `out`; the per-workgroup records go to a fixed array in the library's own
+ * device image (1 MiB per GPU the library runs on, held until the process ends)
+ * instead of the handle's workspace, and the call allocates and frees nothing.
+ * Limits: batches of at most AUV_STATS_MAX_ENVS envs (larger ones fail with
+ * AUV_ERR_ARG and a message); every call on one GPU shares that GPU's array,
+ * so calls that overlap on one GPU (different streams or handles) race -- order
+ * them on one stream.  The array keeps the last call's records; a call reads
+ * back only the records it has just written, so nothing has to be cleared. */
+#define AUV_STATS_MAX_ENVS 1048576
+int auv_episode_stats_static(auv_handle h, double* out, int32_t accumulate, void* stream);
+
 /* ---- dataset text rows (host only, no GPU involved) -------------------------
  * Formats n_rows ragged rows of doubles as the reference's dataset files do
  * (numpy.savetxt defaults: "%.18e", single spaces, "\n"; the files read by
