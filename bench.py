@@ -6,10 +6,17 @@ One step = one pass of the whole path (RKF45 dynamics + navigation, obstacle
 advance, distances / collision / metadata / risk, LiDAR, observation assembly)
 over one batch of synthetic envs, actions already resident in HBM.  The default
 workload is cfg3: 65,536 vessels per GPU, 8 circles + 8 moving 5-edge ships per
-env, 180 rays.  With N > 1 (launched by torch.distributed.run, one rank per
-GPU) every rank steps its own 65,536 envs (weak scaling, no data-path
-collective); the episode-statistic vector is all-reduced once per rollout
-inside the timed region.  Rank 0 prints ONE JSON line.
+env, 180 rays.  With N > 1 every rank steps its own 65,536 envs (weak scaling,
+no data-path collective); the episode-statistic vector is all-reduced once per
+rollout inside the timed region.  Rank 0 prints ONE JSON line.  `--gpus N` run
+as a plain `python bench.py` starts its N ranks itself (torch.distributed.run,
+one rank per GPU, rendezvous on 127.0.0.1) before anything touches a GPU; run
+under torch.distributed.run it takes the ranks it is given, and refuses a
+WORLD_SIZE that differs from N.
+
+The timed rollout (W warm-up steps from the reset state, then K timed steps) is
+repeated `--repeats` times; `value` and `ms_per_step` are the median repeat,
+every repeat being the maximum over ranks.
 
 The timed region carries no instrumentation.  The per-kernel durations behind
 `roofline` come from a second pass of the same K steps, in the same process,
@@ -51,11 +58,13 @@ def sense_bytes_per_env(R, C, P, NV, meta_fields=5):
 VESSEL_BYTES_PER_ENV = 48 + 48 + 16 + 48 + 64 + 16 + 8 + 8 + 24 + 2 + 8  # state rw, action, path, record, own, along rw, nav, flags, t_step
 
 
-def cpu_baseline(name, n_envs, steps, threads):
-    """The oracle on a bounded sample of the same workload, on the host cores:
-    the C restatement (oracle/auv_oracle.c, scalar per env, all ray-primitive
-    pairs) with `threads` threads over disjoint env ranges, plus, for scale,
-    the numpy oracle on one core over a smaller sample."""
+def cpu_baseline(name, n_envs, steps, threads, scalar_envs=4):
+    """The oracle on a bounded sample of the same workload, on the host cores,
+    in three forms: (`value`) the C restatement (oracle/auv_oracle.c, scalar
+    per env, all ray-primitive pairs) with `threads` threads over disjoint env
+    ranges; the numpy oracle vectorised over envs on one core; and the numpy
+    oracle as one object per env stepped one after the other on one core,
+    which is how a gym env runs."""
     from gym_auv_amd import params, scenarios
     from oracle import c_oracle
     from tests.helpers import make_oracle
@@ -80,12 +89,29 @@ def cpu_baseline(name, n_envs, steps, threads):
     for k in range(s_np):
         env2.step(acts[k][:, :n_np])
     dt_np = time.perf_counter() - t1
+    # one env per object, as a gym env is stepped
+    s_sc = min(steps, 25)
+    singles = []
+    for e in range(scalar_envs):
+        one = {k: (v[:, e:e + 1] if k == "init_state" else v[e:e + 1]) for k, v in scene2.items()}
+        cfg1 = dict(cfg2, n_envs=1)
+        env1 = make_oracle(cfg1, one)
+        env1.reset(one["init_state"])
+        singles.append(env1)
+    t2 = time.perf_counter()
+    for e, env1 in enumerate(singles):
+        for k in range(s_sc):
+            env1.step(acts[k][:, e:e + 1])
+    dt_sc = time.perf_counter() - t2
     return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": f"{n_envs} envs x {steps} steps of {name}, C oracle (oracle/auv_oracle.c), {threads} threads, "
                       f"{dt:.1f} s; substitute for the absent reference env",
             "rays_per_s": n_envs * steps * cfg["n_rays"] / dt,
-            "numpy_one_core": {"value": n_np * s_np / dt_np, "unit": "env-steps/s",
-                               "sample": f"{n_np} envs x {s_np} steps, {dt_np:.1f} s"}}
+            "numpy_one_core": {"value": n_np * s_np / dt_np, "unit": "env-steps/s", "cores": 1,
+                               "sample": f"{n_np} envs x {s_np} steps, vectorised over envs, {dt_np:.1f} s"},
+            "numpy_scalar_per_env": {"value": scalar_envs * s_sc / dt_sc, "unit": "env-steps/s", "cores": 1,
+                                     "sample": f"{scalar_envs} envs x {s_sc} steps, one oracle object per env "
+                                               f"stepped in turn, {dt_sc:.1f} s"}}
 
 
 def measured_traffic(key, kernel):
@@ -113,11 +139,58 @@ def measured_valu_insts(key, kernel):
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0
 
 
+def launch_ranks(n):
+    """Re-run this script as n ranks under torch.distributed.run and return its
+    exit status.  Nothing has imported torch or touched a GPU at this point."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def rehearse_without_gpu(args, world, rank):
+    """AUV_BENCH_REHEARSE=nogpu: the launch, rendezvous, barrier, statistics all-reduce and max-over-ranks
+    timing of a multi-rank run on a machine without a GPU (gloo); no simulation runs and the line says so."""
+    import torch
+    import torch.distributed as dist
+
+    from gym_auv_amd import dist as auv_dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    vec = torch.zeros(len(auv_dist.STAT_FIELDS), dtype=torch.float64)
+    vec[0] = 1.0
+    totals = auv_dist.reduce_episode_stats(vec)
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "vessel_env_steps_per_sec", "value": 0.0, "unit": "env-steps/s", "n_gpus": world,
+                          "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f64", "data": "rehearsal without a GPU: no simulation ran",
+                          "config": {"workload": args.workload or "cfg4_8x65536_moving",
+                                     "sharding": f"envs x{world}, no data-path collective"},
+                          "ranks_joined": int(totals["env_steps"])}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if int(totals["env_steps"]) == args.gpus else 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="timed rollouts; the median one is reported")
     ap.add_argument("--workload", default=None,
                     help="default: cfg3_65536_moving on one GPU, cfg4_8x65536_moving (the same scene family, "
                          "65,536 vessels on every GPU) on several")
@@ -147,7 +220,23 @@ def main():
                     help="threads of the CPU baseline (0 = the CPUs this process may use, at most 16)")
     ap.add_argument("--cpu-envs", type=int, default=32768)
     ap.add_argument("--cpu-steps", type=int, default=200)
+    ap.add_argument("--cpu-scalar-envs", type=int, default=4,
+                    help="envs of the scalar-per-env leg of the CPU baseline (numpy oracle, one env per object)")
     args = ap.parse_args()
+    if args.gpus < 1 or args.repeats < 1:
+        ap.error("--gpus and --repeats must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"error: --gpus {args.gpus} but WORLD_SIZE is {world}: start {args.gpus} ranks "
+                  f"(python bench.py --gpus {args.gpus} does it by itself)", file=sys.stderr)
+        sys.exit(2)
+    if os.environ.get("AUV_BENCH_REHEARSE") == "nogpu":
+        sys.exit(rehearse_without_gpu(args, world, rank))
 
     import torch
     import torch.distributed as dist
@@ -156,8 +245,6 @@ def main():
     from gym_auv_amd import dist as auv_dist
     from gym_auv_amd.sim import AuvSim
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal of the multi-rank path on a one-GPU box: AUV_BENCH_REHEARSE=1 puts
     # every rank on cuda:0 and uses gloo (RCCL refuses two ranks on one device)
@@ -170,8 +257,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if world > 1 and dist.get_world_size() != args.gpus:
+        sys.exit(3)   # fewer ranks joined than asked for
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -198,10 +285,7 @@ def main():
     n_act = 8
     acts = torch.from_numpy(scenarios.random_actions(V, n_act, seed=100 + rank)).to(dev)
     ptrs = [acts[i].data_ptr() for i in range(n_act)]
-    done_t, coll_t, rew_t = sim.tensor("done"), sim.tensor("collision"), sim.tensor("reward")
-    goal_t, trunc_t = sim.tensor("reached_goal"), sim.tensor("truncated")
     per_all = sim.tensor("perception")
-    ranges_t, risk_t = sim.tensor("ranges"), sim.tensor("risk")
 
     # the consumer of the scans: the reference's shipped weights (fixture made from its own files)
     net = feats = per_t = None
@@ -234,7 +318,7 @@ def main():
         # episode statistics of a rollout: one small all-reduce (RCCL), not per step;
         # optionally the last scans of every rank gathered on the trainer rank 0
         st = auv_dist.EpisodeStats(dev)
-        st.update(done_t, coll_t, goal_t, trunc_t, rew_t, ranges=ranges_t, risk=risk_t)
+        st.update_from_sim(sim, stream=stream)
         totals = st.reduce()
         if args.gather_scans and per_all is not None:
             auv_dist.gather_scans(per_all, dst=0)
@@ -264,12 +348,15 @@ def main():
             sim.step_device(ptrs[k % n_act], stream=stream)
 
     prepare()
-    episode_stats()   # loads torch's reduction kernels / sets up the communicator outside the timed region
-    sync_all()
-    t0 = time.perf_counter()
-    stats = rollout()
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    episode_stats()   # sets up the communicator outside the timed region
+    times = []
+    for rep in range(args.repeats):
+        prepare()
+        sync_all()
+        t0 = time.perf_counter()
+        stats = rollout()
+        sync_all()
+        times.append(time.perf_counter() - t0)
 
     # second pass, instrumented: HIP events around every kernel, on the launch stream
     prepare()
@@ -291,10 +378,11 @@ def main():
         e1.synchronize()
         cnn_ms = e0.elapsed_time(e1) / args.steps
 
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    t = torch.tensor(times, device=dev, dtype=torch.float64)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # every repeat: the slowest rank
+    times = sorted(t.tolist())
+    elapsed = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
 
     if rank == 0:
         S = P * NV
@@ -310,6 +398,7 @@ def main():
             "rays_per_sec": env_steps * R / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "repeats": args.repeats, "ms_per_step_all": [x / args.steps * 1e3 for x in t.tolist()],
             "ms_per_step_with_events": ev_elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -354,8 +443,9 @@ def main():
                 out["valu_issue"] = {
                     "kernel": "k_sense", "achieved": vi / sense_s, "peak": VALU_ISSUE_PEAK, "unit": "wave-instr/s",
                     "frac": vi / sense_s / VALU_ISSUE_PEAK, "insts_per_launch": vi,
-                    "note": "executed VALU wave-instructions (PMC, profiles/) over this run's launch time, against "
-                            "the issue rate of 1024 SIMDs at 2.4 GHz: what actually bounds the kernel"}
+                    "note": "executed VALU wave-instructions per launch, from the committed PMC pass over a "
+                            "200-step rollout of this workload (profiles/traffic.json), over THIS run's average launch "
+                            f"time ({args.steps} steps), against the issue rate of 1024 SIMDs at 2.4 GHz"}
             vb = float(VESSEL_BYTES_PER_ENV) * V
             out["roofline_vessel"] = {
                 "kernel": "k_vessel", "bound": "hbm", "achieved": vb / vessel_s / 1e9, "peak": HBM_PEAK_GBS,
@@ -376,7 +466,8 @@ def main():
                 "note": "fp64 vector (non-MFMA) roofline; (16*circles + 18*edges) flop per ray"}
         if not args.no_cpu_baseline and world == 1:
             threads = args.cpu_threads or max(1, min(16, len(os.sched_getaffinity(0))))
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_envs, args.cpu_steps, threads)
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_envs, args.cpu_steps, threads,
+                                               args.cpu_scalar_envs)
         print(json.dumps(out), flush=True)
     sim.close()
     if world > 1:

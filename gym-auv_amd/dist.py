@@ -69,10 +69,13 @@ def reduce_episode_stats(vec: torch.Tensor, group=None) -> dict:
     return dict(zip(STAT_FIELDS, total.tolist()))
 
 
-def gather_scans(perception: torch.Tensor, dst: int = 0, group=None):
+def gather_scans(perception: torch.Tensor, dst: int = 0, group=None, out: torch.Tensor | None = None):
     """Gather every rank's scans `[V_local,1,R]` on rank `dst`, in rank order
     (= env order of the block sharding).  Returns `[V_total,1,R]` on `dst`,
-    None elsewhere.  Shards may differ in size by one env."""
+    None elsewhere.  Equal shards (the benchmark's case) land directly in the
+    slices of ONE result tensor (`out`, or a new one): no padding, no
+    concatenation, nothing copied twice on the trainer.  Shards that differ in
+    size by an env are padded to the longest for the collective."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return perception
     world = dist.get_world_size(group)
@@ -81,12 +84,22 @@ def gather_scans(perception: torch.Tensor, dst: int = 0, group=None):
     sizes[rank] = perception.shape[0]
     dist.all_reduce(sizes, group=group)
     sizes = sizes.tolist()
-    vmax = max(sizes)
-    send = perception
-    if perception.shape[0] < vmax:   # gather needs equal shapes: pad the short shards
-        pad = perception.new_zeros((vmax - perception.shape[0],) + tuple(perception.shape[1:]))
-        send = torch.cat([perception, pad], dim=0)
-    send = send.contiguous()
+    vmax, total = max(sizes), sum(sizes)
+    tail = tuple(perception.shape[1:])
+    send = perception.contiguous()
+    if min(sizes) == vmax:
+        if rank != dst:
+            dist.gather(send, None, dst=dst, group=group)
+            return None
+        if out is None:
+            out = torch.empty((total,) + tail, dtype=perception.dtype, device=perception.device)
+        elif tuple(out.shape) != (total,) + tail or out.dtype != perception.dtype or not out.is_contiguous():
+            raise ValueError(f"gather_scans: out must be a contiguous {(total,) + tail} tensor of {perception.dtype}")
+        dist.gather(send, list(out.split(vmax, dim=0)), dst=dst, group=group)   # views of `out`: written in place
+        return out
+    if perception.shape[0] < vmax:
+        pad = perception.new_zeros((vmax - perception.shape[0],) + tail)
+        send = torch.cat([perception, pad], dim=0).contiguous()
     if rank == dst:
         bufs = [torch.empty_like(send) for _ in range(world)]
         dist.gather(send, bufs, dst=dst, group=group)

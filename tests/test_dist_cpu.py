@@ -98,3 +98,64 @@ def test_single_process_paths_need_no_group():
     z = torch.zeros(5, dtype=torch.uint8)
     s.update(z, z, z, z, torch.ones(5, dtype=torch.float64))
     assert s.reduce()["reward_sum"] == 5.0
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = torch.full((6, 1, 180), float(rank + 1)) + torch.arange(180.0) / 1000.0
+        out = torch.zeros((12, 1, 180)) if rank == 0 else None
+        got = D.gather_scans(mine, dst=0, out=out)
+        if rank == 0:
+            assert got is out                       # equal shards land in the caller's tensor, in place
+            q.put(out.numpy())
+            with pytest.raises(ValueError):
+                D.gather_scans(mine, dst=0, out=torch.zeros((11, 1, 180)))
+        else:
+            assert got is None
+            q.put(None)
+    finally:
+        tdist.destroy_process_group()
+
+
+def test_equal_shards_gather_in_place():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    out = [g for g in got if g is not None][0]
+    want = np.concatenate([np.full((6, 1, 180), k + 1.0, dtype=np.float32) + np.arange(180, dtype=np.float32) / 1000.0
+                           for k in range(2)])
+    assert np.array_equal(out, want.astype(np.float32))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2`, not under torchrun, must come back as a two-rank run.  There is no GPU here, so
+    the ranks rehearse everything but the simulation (AUV_BENCH_REHEARSE=nogpu): launch, rendezvous, barrier,
+    the statistics all-reduce, the one JSON line of rank 0."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["AUV_BENCH_REHEARSE"] = "nogpu"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_joined"] == 2 and out["config"]["sharding"].startswith("envs x2")
+    # a rank count that differs from --gpus is refused, not silently measured
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr

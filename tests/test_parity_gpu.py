@@ -238,17 +238,19 @@ def test_full_size_restarts_with_regeneration_against_oracle_sample():
     env.reset(None)
     acts = scenarios.random_actions(V, steps, seed=10)
     acts[:, 0] = 1.0
+    ended_early = 0   # episodes of the whole batch seen ending by contact or arrival, not by truncation
     for k in range(steps):
         sim.step_host(acts[k])
         env.step(acts[k][:, pick])
         if k % 3 == 2 or k == steps - 1:
+            ended_early += int((sim.read("collision") | sim.read("reached_goal")).sum())
             for name, attr in PAIRS.items():
                 got = sim.read(name)
                 got = got[:, pick] if name == "state" else got[pick]
                 want = np.asarray(getattr(env, attr)).reshape(got.shape)
                 assert same_bits(got, want), (name, k)
     ep = sim.read("episode")
-    assert ep.min() >= 3 and env.collision.sum() + env.reached_goal.sum() >= 0
+    assert ep.min() >= 3 and ended_early > 0
     sim.close()
 
 
@@ -396,20 +398,22 @@ def test_full_size_batch_against_oracle_sample():
     sim.close()
 
 
-@pytest.mark.parametrize("name,steps,mode", [("cfg3_65536_moving", 10, 0), ("cfg3_65536_moving", 3, 1),
-                                             ("cfg2_4096_static", 10, 0), ("cfg5_dense_720", 2, 0)],
-                         ids=["cfg3-raster", "cfg3-allpairs", "cfg2", "cfg5"])
-def test_full_size_batch_every_env_against_c_oracle(name, steps, mode):
+@pytest.mark.parametrize("name,steps,mode,rank", [("cfg3_65536_moving", 10, 0, 0), ("cfg3_65536_moving", 3, 1, 0),
+                                                  ("cfg2_4096_static", 10, 0, 0), ("cfg5_dense_720", 2, 0, 0),
+                                                  ("cfg4_8x65536_moving", 6, 0, 5)],
+                         ids=["cfg3-raster", "cfg3-allpairs", "cfg2", "cfg5", "cfg4-shard-of-rank-5"])
+def test_full_size_batch_every_env_against_c_oracle(name, steps, mode, rank):
     """The benchmark configurations at their FULL sizes (65,536 vessels; 4,096
     vessels with 720 rays and 256 obstacles), every env and every buffer, bit
     for bit, against the C restatement of the oracle (itself pinned to the numpy
     text by tests/test_c_oracle_cpu.py) run on the host cores, after the reset
-    and after every step."""
+    and after every step.  The 8-GPU configuration is covered by the 65,536 envs
+    that one of its ranks (rank 5) simulates: ranks share nothing while stepping."""
     import os
 
     from oracle import c_oracle
 
-    cfg, scene = scenarios.make_workload(name)
+    cfg, scene = scenarios.make_workload(name, rank=rank)
     V = cfg["n_envs"]
     sim = make_sim(cfg, scene, lidar_mode=mode)
     threads = max(1, min(16, len(os.sched_getaffinity(0))))
