@@ -235,6 +235,11 @@ def main():
             print(f"error: --gpus {args.gpus} but WORLD_SIZE is {world}: start {args.gpus} ranks "
                   f"(python bench.py --gpus {args.gpus} does it by itself)", file=sys.stderr)
         sys.exit(2)
+    if os.environ.get("AUV_BENCH_WATCHDOG"):
+        # diagnostic: dump every thread's stack and exit if the run is still going after that many seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["AUV_BENCH_WATCHDOG"]), exit=True)
     if os.environ.get("AUV_BENCH_REHEARSE") == "nogpu":
         sys.exit(rehearse_without_gpu(args, world, rank))
 
@@ -379,8 +384,7 @@ def main():
         cnn_ms = e0.elapsed_time(e1) / args.steps
 
     t = torch.tensor(times, device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # every repeat: the slowest rank
+    auv_dist.all_reduce(t, op=dist.ReduceOp.MAX)   # every repeat: the slowest rank
     times = sorted(t.tolist())
     elapsed = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
 

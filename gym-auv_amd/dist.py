@@ -61,12 +61,25 @@ class EpisodeStats:
         return reduce_episode_stats(self.vec, group)
 
 
+def all_reduce(t: torch.Tensor, op=dist.ReduceOp.SUM, group=None) -> torch.Tensor:
+    """In-place all-reduce of a small tensor.  RCCL reduces device tensors in
+    place; a gloo group (CPU tests, the one-GPU rehearsal of the multi-rank
+    path) gets a host copy, because gloo's handling of device tensors stalls
+    when several ranks share one GPU."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 def reduce_episode_stats(vec: torch.Tensor, group=None) -> dict:
     """all-reduce(sum) of the statistics vector over all ranks."""
-    total = vec.clone()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
-    return dict(zip(STAT_FIELDS, total.tolist()))
+    return dict(zip(STAT_FIELDS, all_reduce(vec.clone(), group=group).tolist()))
 
 
 def gather_scans(perception: torch.Tensor, dst: int = 0, group=None, out: torch.Tensor | None = None):
@@ -80,10 +93,17 @@ def gather_scans(perception: torch.Tensor, dst: int = 0, group=None, out: torch.
         return perception
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    sizes = torch.zeros(world, dtype=torch.int64, device=perception.device)
+    sizes = torch.zeros(world, dtype=torch.int64)
     sizes[rank] = perception.shape[0]
+    if dist.get_backend(group) != "gloo":
+        sizes = sizes.to(perception.device)
     dist.all_reduce(sizes, group=group)
     sizes = sizes.tolist()
+    if perception.is_cuda and dist.get_backend(group) == "gloo":
+        got = gather_scans(perception.cpu(), dst, group, None if out is None else out.cpu())
+        if got is None:
+            return None
+        return got.to(perception.device) if out is None else out.copy_(got)
     vmax, total = max(sizes), sum(sizes)
     tail = tuple(perception.shape[1:])
     send = perception.contiguous()
