@@ -370,8 +370,20 @@ inline bool is_default_shape(const Dims& d, int te, int block, int cap) {
 
 // RISK: 0 = default risk index, 1 = the reference's index (auv_risk.hpp)
 // FIXED: the shape is DefaultShape (checked by the launcher)
+typedef const __attribute__((address_space(4))) SenseArgs* KernArgs;
+// The kernel's arguments re-read from the kernarg segment at the point of the call: values fetched here are not
+// held in scalar registers (or spilled to vector lanes) from the launch on.
+__device__ __forceinline__ SenseArgs reload_args() {
+    KernArgs p = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    SenseArgs r;
+    __builtin_memcpy(&r, (const SenseArgs*)p, sizeof(SenseArgs));
+    return r;
+}
+
 template <int RISK, bool FIXED>
-__device__ __forceinline__ void sense_tile(const SenseArgs& a) {
+__device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
+    const SenseArgs& a = a0;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int V = a.d.V;
     const int R = FIXED ? DefaultShape::R : a.d.R, C = FIXED ? DefaultShape::C : a.d.C, P = FIXED ? DefaultShape::P : a.d.P;
@@ -647,6 +659,8 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a) {
     // the deferred write-back of the advanced position), relative speed and
     // the per-env summary; 1 = bearing; 2 = course; 3 = risk.
     {
+        const SenseArgs a2 = reload_args();
+        const SenseArgs& a = a2;
         const int n_waves = nthr >> 6;
         const int wave = tid >> 6;
         const int n_obst = ne * O;
@@ -867,30 +881,32 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a) {
 
     // ---- phase 4: 16 B per ray, coalesced; the attached network's weights
     // come in meanwhile
+    const SenseArgs a4 = reload_args();
+    const SenseArgs& a_out = a4;
     float* cnn_lds = reinterpret_cast<float*>(lds_raw);  // weights, then 2 activation buffers per env
-    const int n_w = a.cnn_w ? cnn_n_weights(a.cnn_kind) : 0;
+    const int n_w = a_out.cnn_w ? cnn_n_weights(a_out.cnn_kind) : 0;
     float w_mine = 0.f;
-    if (tid < n_w) w_mine = a.cnn_w[tid];
+    if (tid < n_w) w_mine = a_out.cnn_w[tid];
     for (int f = tid; f < ne * R; f += nthr) {
         const double t = __longlong_as_double((long long)best[f]);
         const size_t out = (size_t)e0 * R + f;
-        const float close = (float)(1.0 - div_by_const(t, range, a.inv_range));
-        a.ranges[out] = t;
-        a.hit[out] = (int)ids[f];
-        a.perception[out] = close;
-        if (a.cnn_w) reinterpret_cast<float*>(ids)[f] = close;  // the id slot becomes the network's input
+        const float close = (float)(1.0 - div_by_const(t, range, a_out.inv_range));
+        a_out.ranges[out] = t;
+        a_out.hit[out] = (int)ids[f];
+        a_out.perception[out] = close;
+        if (a_out.cnn_w) reinterpret_cast<float*>(ids)[f] = close;  // the id slot becomes the network's input
     }
-    if (a.cnn_w) {
+    if (a_out.cnn_w) {
         if (tid < n_w) cnn_lds[tid] = w_mine;
-        for (int i = tid + nthr; i < n_w; i += nthr) cnn_lds[i] = a.cnn_w[i];
+        for (int i = tid + nthr; i < n_w; i += nthr) cnn_lds[i] = a_out.cnn_w[i];
         __syncthreads();
         // the tile's scans together, output elements dealt over the workgroup;
         // each is summed by one thread in the order k_cnn uses: same values
         float* act = cnn_lds + ((n_w + 3) & ~3);
-        cnn_forward<false, true>(reinterpret_cast<const float*>(ids), R, act, act + cnn_p_floats(a.cnn_kind),
-                                 cnn_act_floats(a.cnn_kind), ne, cnn_lds,
-                                 a.cnn_out + (size_t)e0 * cnn_out_dim(a.cnn_kind, a.cnn_head), a.cnn_kind,
-                                 a.cnn_head, tid, nthr);
+        cnn_forward<false, true>(reinterpret_cast<const float*>(ids), R, act, act + cnn_p_floats(a_out.cnn_kind),
+                                 cnn_act_floats(a_out.cnn_kind), ne, cnn_lds,
+                                 a_out.cnn_out + (size_t)e0 * cnn_out_dim(a_out.cnn_kind, a_out.cnn_head), a_out.cnn_kind,
+                                 a_out.cnn_head, tid, nthr);
     }
     AUV_STAMP(9);
 }
