@@ -78,9 +78,14 @@ class LidarCNN:
             raise ValueError("scans must be a contiguous float32 CUDA tensor")
         if scans.dim() != 3 or scans.shape[1] != 1 or scans.shape[2] != 180:
             raise ValueError(f"scans must be (B,1,180), got {tuple(scans.shape)}")
+        if scans.device.index != self.device:
+            raise ValueError(f"scans on cuda:{scans.device.index}, network on cuda:{self.device}")
         B = scans.shape[0]
         if out is None:
             out = torch.empty((B, self.out_dim(head)), dtype=torch.float32, device=scans.device)
+        elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.device == scans.device
+                  and tuple(out.shape) == (B, self.out_dim(head))):
+            raise ValueError(f"out must be a contiguous float32 ({B}, {self.out_dim(head)}) tensor on {scans.device}")
         if B == 0:
             return out
         st = torch.cuda.current_stream(scans.device).cuda_stream

@@ -18,18 +18,22 @@
 
 namespace auvfmt {
 
-inline const uint64_t* pow5_table() {
-    static uint64_t t[28];
-    static bool ready = false;
-    if (!ready) {
+struct Pow5Table {
+    uint64_t t[28];
+    Pow5Table() {
         uint64_t p = 1;
         for (int i = 0; i < 28; ++i) {
             t[i] = p;
             p *= 5;
         }
-        ready = true;
     }
-    return t;
+};
+
+// 5^0 .. 5^27; a function-local static of class type is initialised exactly once even when the
+// formatter's worker threads arrive together
+inline const uint64_t* pow5_table() {
+    static const Pow5Table table;
+    return table.t;
 }
 
 // digits of N * 2^-s... see header.  Returns false when v is outside the fast range.

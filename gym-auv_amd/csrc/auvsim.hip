@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstddef>
 #include <cstdio>
@@ -97,6 +98,8 @@ struct auv_sim {
     uint8_t* mask_stage = nullptr;
     double* stats_ws = nullptr;    // [stats_blocks(V), kStatsFields] records of k_stats_partial
     bool have_rays = false, have_scene = false, have_state = false;
+    bool custom_rays = false;  // the ray table is not the evenly spaced full circle the rasterising path indexes by
+    int32_t scene_upto = 0;    // envs [0, scene_upto) have been uploaded (auv_set_scene sweeps front to back)
     // launch geometry
     int lidar_te = 1, lidar_block = 256, enc_eb = 1;
     size_t lidar_lds = 0, enc_lds = 0;
@@ -529,7 +532,9 @@ int drain_profile(auv_sim* h) {
 
 int ready_to_run(auv_sim* h, bool need_state) {
     if (!h->have_rays) return fail(h, AUV_ERR_STATE, "auv_set_rays has not been called");
-    if (!h->have_scene) return fail(h, AUV_ERR_STATE, "auv_set_scene has not covered every env yet");
+    if (!h->have_scene)
+        return fail(h, AUV_ERR_STATE, "auv_set_scene has not covered every env yet: envs [%d, %d) are missing "
+                    "(upload front to back)", h->scene_upto, h->d.V);
     if (need_state && !h->have_state) return fail(h, AUV_ERR_STATE, "auv_reset has not been called");
     return AUV_OK;
 }
@@ -718,9 +723,23 @@ void auv_destroy(auv_handle h) {
 
 int auv_set_rays(auv_handle h, const double* ray_dirs) {
     if (!h || !ray_dirs) return fail(h, AUV_ERR_ARG, "auv_set_rays: null argument");
+    // The rasterising kernel picks candidate rays by index arithmetic that assumes ray i at body angle
+    // -pi + (i + 1) 2 pi / R.  Any other table (a sector sensor, another start, uneven spacing) takes the
+    // all-pairs path, which reads the directions only.
+    const int R = h->d.R;
+    bool custom = false;
+    for (int i = 0; i < R && !custom; ++i) {
+        const double ang = -3.141592653589793 + (i + 1.0) * (6.283185307179586 / R);
+        custom = std::fabs(ray_dirs[2 * i] - std::cos(ang)) > 1e-9 || std::fabs(ray_dirs[2 * i + 1] - std::sin(ang)) > 1e-9;
+    }
+    if (custom && h->auto_reset)
+        return fail(h, AUV_ERR_ARG, "auv_set_rays: this ray table is not the evenly spaced full circle; it needs the "
+                    "all-pairs path, which has no in-step restart (clear AUV_OPT_AUTO_RESET first)");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpy(h->ray_dirs, ray_dirs, (size_t)h->d.R * 2 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->ray_dirs, ray_dirs, (size_t)R * 2 * sizeof(double), hipMemcpyHostToDevice));
     h->have_rays = true;
+    h->custom_rays = custom;
+    if (custom) h->lidar_mode = AUV_LIDAR_ALL_PAIRS;
     return AUV_OK;
 }
 
@@ -784,11 +803,11 @@ int auv_set_scene(auv_handle h, int32_t env_begin, int32_t env_count, const doub
         HIP_TRY(h, hipMemcpy(h->poly_rot + b * d.P * d.NV * 2, rot.data(), rot.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     if (path) HIP_TRY(h, hipMemcpy(h->path + b * 6, path, n * 6 * sizeof(double), hipMemcpyHostToDevice));
-    // the scene counts as complete once one call has covered all envs, or the
-    // calls so far were a front-to-back sweep ending at V
+    // the scene is complete once the calls so far have covered [0, V): each call may extend the covered
+    // prefix (or rewrite envs inside it)
     h->heading_stale = true;
-    if (env_begin == 0 && env_count == d.V) h->have_scene = true;
-    else if (env_begin + env_count == d.V) h->have_scene = true;
+    if (env_begin <= h->scene_upto && env_begin + env_count > h->scene_upto) h->scene_upto = env_begin + env_count;
+    if (h->scene_upto == d.V) h->have_scene = true;
     return AUV_OK;
 }
 
@@ -983,6 +1002,9 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
                 return fail(h, AUV_ERR_ARG, "auv_set_option: unknown LiDAR mode %d", value);
             if (value == AUV_LIDAR_ALL_PAIRS && h->auto_reset)
                 return fail(h, AUV_ERR_ARG, "auv_set_option: the all-pairs path has no in-step restart; clear AUV_OPT_AUTO_RESET first");
+            if (value == AUV_LIDAR_RASTER && h->custom_rays)
+                return fail(h, AUV_ERR_ARG, "auv_set_option: the rasterising path needs the evenly spaced full-circle ray "
+                            "table (ray i at -pi + (i+1) 2pi/R); the table set by auv_set_rays differs");
             if (value == AUV_LIDAR_RASTER && h->raster_lds > kLdsMax)
                 return fail(h, AUV_ERR_ARG, "auv_set_option: rasterising LiDAR needs %zu B of LDS per env (limit 163840)",
                             h->raster_lds);
@@ -1020,8 +1042,16 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
         case AUV_OPT_RASTER_TILE:
             if (value < 0 || value > 64)
                 return fail(h, AUV_ERR_ARG, "auv_set_option: envs per workgroup must be 0 (auto) or 1..64");
+        {
+            const int before = h->raster_want;
             set_raster_tile(h, value);
+            if (h->raster_lds > kLdsMax) {
+                const size_t need = h->raster_lds;
+                set_raster_tile(h, before);
+                return fail(h, AUV_ERR_ARG, "auv_set_option: a tile of %d envs needs %zu B of LDS (limit 163840)", value, need);
+            }
             return AUV_OK;
+        }
     }
     return fail(h, AUV_ERR_ARG, "auv_set_option: unknown key %d", key);
 }
@@ -1281,14 +1311,26 @@ int auv_attach_cnn(auv_handle h, auv_cnn_handle c, int32_t head) {
         (void)hipFree(w);
         return fail(h, AUV_ERR_DEVICE, "auv_attach_cnn: weight copy failed");
     }
-    if (h->cnn_w) (void)hipFree(h->cnn_w);
+    float* old_w = h->cnn_w;
+    const int old_kind = h->cnn_kind, old_head = h->cnn_head;
     h->cnn_w = w;
     h->cnn_kind = c->kind;
     h->cnn_head = head;
+    set_raster_tile(h, h->raster_want);  // the activation buffers change the LDS image
+    if (h->raster_lds > kLdsMax && h->lidar_mode == AUV_LIDAR_RASTER) {
+        // the image no longer fits: refuse rather than change the sensing path (and lose the in-step restart) silently
+        const size_t need = h->raster_lds;
+        h->cnn_w = old_w;
+        h->cnn_kind = old_kind;
+        h->cnn_head = old_head;
+        set_raster_tile(h, h->raster_want);
+        (void)hipFree(w);
+        return fail(h, AUV_ERR_ARG, "auv_attach_cnn: with this network in the sensing kernel one env needs %zu B of LDS "
+                    "(limit 163840); select AUV_LIDAR_ALL_PAIRS first or run the network with auv_cnn_forward", need);
+    }
+    if (old_w) (void)hipFree(old_w);
     b.shape[1] = cnn_out_dim(c->kind, head);
     b.bytes = (size_t)b.shape[0] * (size_t)b.shape[1] * sizeof(float);
-    set_raster_tile(h, h->raster_want);  // the activation buffers change the LDS image
-    if (h->raster_lds > kLdsMax) h->lidar_mode = AUV_LIDAR_ALL_PAIRS;
     return AUV_OK;
 }
 

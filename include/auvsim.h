@@ -163,10 +163,18 @@ const char* auv_last_error(auv_handle h);
 int auv_create(const auv_config* cfg, int device, auv_handle* out);
 void auv_destroy(auv_handle h);
 
-/* Body-frame ray directions, host f64 [R,2] = (cos, sin) per ray. */
+/* Body-frame ray directions, host f64 [R,2] = (cos, sin) per ray.  The
+ * rasterising path (AUV_LIDAR_RASTER, the default) indexes rays by angle and
+ * needs the evenly spaced full circle, ray i at -pi + (i + 1) 2 pi / R (what
+ * the reference's 180-ray scan is pinned to, to +-2 rays, by its logged rows
+ * and shipped networks); a table that differs from it by more than 1e-9
+ * switches the batch to AUV_LIDAR_ALL_PAIRS, which reads the directions only,
+ * and AUV_LIDAR_RASTER is then refused by auv_set_option. */
 int auv_set_rays(auv_handle h, const double* ray_dirs);
 
-/* Upload scene data for envs [env_begin, env_begin+env_count); all host
+/* Upload scene data for envs [env_begin, env_begin+env_count), front to back
+ * (a call may start anywhere inside the part already uploaded); stepping needs
+ * every env covered.  All host
  * pointers: circles f64 [n,C,5], poly_pose f64 [n,P,6], poly_verts f64
  * [n,P,NV,2], poly_nv i32 [n,P], poly_heading f64 [n,P], path f64 [n,6].
  * A pointer may be NULL when its slot count is 0 (path NULL keeps paths). */

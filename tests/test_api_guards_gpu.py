@@ -1,0 +1,110 @@
+"""Inputs the fast paths cannot serve must be routed or refused, never served wrongly."""
+import numpy as np
+import pytest
+
+from gym_auv_amd import _lib, cnn, params, scenarios
+from gym_auv_amd.sim import AuvSim
+from oracle import auv_oracle as O
+from oracle import cnn_oracle as N
+from tests.helpers import PAIRS, same_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def sector_table(n_rays, lo=-1.0, hi=1.0):
+    ang = np.linspace(lo, hi, n_rays)
+    return np.ascontiguousarray(np.stack([np.cos(ang), np.sin(ang)], axis=1))
+
+
+@pytest.mark.parametrize("table", ["sector", "turned", "uneven"])
+def test_custom_ray_table_takes_the_all_pairs_path_and_matches_the_oracle(table):
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=300)
+    R = cfg["n_rays"]
+    if table == "sector":
+        rays = sector_table(R)
+    elif table == "turned":
+        ang = -np.pi + (np.arange(R) + 1.5) * (2 * np.pi / R)      # half a ray off the standard layout
+        rays = np.ascontiguousarray(np.stack([np.cos(ang), np.sin(ang)], axis=1))
+    else:
+        ang = np.sort(np.random.default_rng(5).uniform(-np.pi, np.pi, R))
+        rays = np.ascontiguousarray(np.stack([np.cos(ang), np.sin(ang)], axis=1))
+    sim = AuvSim(cfg, ray_dirs=rays)
+    with pytest.raises(_lib.AuvError, match="evenly spaced"):
+        sim.set_option(_lib.OPT_LIDAR_MODE, _lib.LIDAR_RASTER)
+    with pytest.raises(_lib.AuvError):
+        sim.set_option(_lib.OPT_AUTO_RESET, 1)
+    sim.set_scene(scene)
+    env = O.OracleEnv(cfg, rays)
+    env.set_scene(scene["circles"], scene["poly_pose"], scene["poly_verts"], scene["poly_nv"], scene["poly_heading"])
+    env.set_path(scene["path"])
+    sim.reset(scene["init_state"])
+    env.reset(scene["init_state"])
+    acts = scenarios.random_actions(300, 3, seed=2)
+    for k in range(3):
+        sim.step_host(acts[k])
+        env.step(acts[k])
+        for name, attr in PAIRS.items():
+            got = sim.read(name)
+            assert same_bits(got, np.asarray(getattr(env, attr)).reshape(got.shape)), (name, k)
+    assert (env.hit >= 0).any()
+    # the standard table again: the rasterising path is available again
+    sim.set_rays(params.ray_table(R))
+    sim.set_option(_lib.OPT_LIDAR_MODE, _lib.LIDAR_RASTER)
+    sim.close()
+
+
+def test_custom_rays_refused_while_in_step_restart_is_on():
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=16)
+    sim = AuvSim(cfg)
+    sim.set_option(_lib.OPT_AUTO_RESET, 1)
+    with pytest.raises(_lib.AuvError, match="in-step restart"):
+        sim.set_rays(sector_table(cfg["n_rays"]))
+    sim.close()
+
+
+def test_partial_scene_upload_is_not_a_complete_scene():
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=40)
+    sim = AuvSim(cfg)
+    tail = {k: (v[:, 30:] if k == "init_state" else v[30:]) for k, v in scene.items()}
+    sim.set_scene(tail, env_begin=30)                 # only the last shard
+    with pytest.raises(_lib.AuvError, match=r"envs \[0, 40\) are missing"):
+        sim.reset(scene["init_state"])
+    head = {k: (v[:, :30] if k == "init_state" else v[:30]) for k, v in scene.items()}
+    sim.set_scene(head, env_begin=0)
+    with pytest.raises(_lib.AuvError, match=r"envs \[30, 40\) are missing"):
+        sim.reset(scene["init_state"])
+    sim.set_scene(tail, env_begin=30)
+    sim.reset(scene["init_state"])                    # front to back: complete
+    sim.close()
+
+
+def test_oversized_tile_request_is_cut_down_to_what_fits():
+    cfg, scene = scenarios.make_workload("cfg5_dense_720", n_envs=64)
+    sim = AuvSim(cfg)
+    sim.set_option(_lib.OPT_RASTER_TILE, 64)          # 64 envs x 1,152 primitives cannot share one LDS image
+    sim.set_scene(scene)
+    sim.reset(scene["init_state"])                    # launches with the largest tile that fits
+    env = O.OracleEnv(cfg, params.ray_table(cfg["n_rays"]))
+    env.set_scene(scene["circles"], scene["poly_pose"], scene["poly_verts"], scene["poly_nv"], scene["poly_heading"])
+    env.set_path(scene["path"])
+    env.reset(scene["init_state"])
+    assert same_bits(sim.read("ranges"), env.ranges) and same_bits(sim.read("hit"), env.hit)
+    with pytest.raises(_lib.AuvError):
+        sim.set_option(_lib.OPT_RASTER_TILE, 65)
+    sim.close()
+
+
+def test_cnn_forward_checks_its_output_tensor():
+    import os
+
+    import torch
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "cnn_golden.npz"))
+    net = cnn.LidarCNN("shallow", N.golden_weights(gold, "shallow"))
+    x = torch.rand(5, 1, 180, device="cuda")
+    for bad in (torch.empty(5, 1, dtype=torch.float64, device="cuda"), torch.empty(4, 1, device="cuda"),
+                torch.empty(5, 12, device="cuda"), torch.empty(5, 2, device="cuda")[:, :1], torch.empty(5, 1)):
+        with pytest.raises(ValueError):
+            net.forward(x, "risk", out=bad)
+    assert net.forward(x, "risk", out=torch.empty(5, 1, device="cuda")).shape == (5, 1)
+    net.close()
