@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AUVSIM_LIB points diagnostic runs at another build of the same library
 LIB_PATH = os.environ.get("AUVSIM_LIB") or os.path.join(_HERE, "libauvsim.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 N_MODEL = 16
 
 # auv_dtype
@@ -40,6 +40,7 @@ OPT_RISK_MODEL = 6
 LIDAR_RASTER, LIDAR_ALL_PAIRS = 0, 1
 RISK_CPA, RISK_REFERENCE = 0, 1
 STATS_FIELDS = 8
+SIZES_UNIFORM, SIZES_BELL = 0, 1
 STATS_MAX_ENVS = 1048576
 
 # CNN consumers
@@ -72,7 +73,7 @@ class AuvConfig(C.Structure):
 
 class AuvSceneParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("extent", "r_lo", "r_hi", "w_lo", "w_hi", "s_lo", "s_hi", "clearance",
-                                          "path_length")]
+                                          "path_length")] + [("size_law", C.c_int32), ("reserved", C.c_int32)]
 
 
 class AuvError(RuntimeError):

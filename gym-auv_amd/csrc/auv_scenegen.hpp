@@ -31,7 +31,7 @@ __host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
     return Philox4{c0, c1, c2, c3};
 }
 
-enum ScenePurpose { SG_VESSEL = 0, SG_CIRCLE_POS, SG_CIRCLE_RAD, SG_POLY_POS, SG_POLY_MOTION, SG_POLY_WIDTH };
+enum ScenePurpose { SG_VESSEL = 0, SG_CIRCLE_POS, SG_CIRCLE_RAD, SG_POLY_POS, SG_POLY_MOTION, SG_POLY_WIDTH, SG_POLY_SPEED };
 
 struct Uniform2 {
     double a, b;
@@ -65,7 +65,14 @@ struct SceneGenArgs {
     double* path;  // [V,6]
     double* init;  // [6,V]
     double extent, r_lo, r_hi, w_lo, w_hi, s_lo, s_hi, clearance, path_length;
+    int size_law;  // 0: uniform; 1: whole-number sizes and speeds with a triangular law
 };
+
+// a size in [lo, hi]: uniform from u, or (bell) a whole number lo..hi from the mean of two uniforms
+__device__ __forceinline__ double draw_size(double lo, double hi, Uniform2 u, int bell) {
+    if (bell) return __builtin_floor(lo + ((hi + 1.0) - lo) * ((u.a + u.b) * 0.5));
+    return lo + (hi - lo) * u.a;
+}
 
 __device__ __forceinline__ void push_out(double& x, double& y, double clear) {
     double d = __builtin_sqrt(x * x + y * y);
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256) void k_scenegen(SceneGenArgs a) {
         const int j = slot - 1;
         const Uniform2 up = uniform2(a.seed, e, ep, SG_CIRCLE_POS, j);
         const Uniform2 ur = uniform2(a.seed, e, ep, SG_CIRCLE_RAD, j);
-        const double rad = a.r_lo + (a.r_hi - a.r_lo) * ur.a;
+        const double rad = draw_size(a.r_lo, a.r_hi, ur, a.size_law);
         double cx = up.a * (2.0 * E) - E;
         double cy = up.b * (2.0 * E) - E;
         push_out(cx, cy, rad + a.clearance);
@@ -120,8 +127,12 @@ __global__ __launch_bounds__(256) void k_scenegen(SceneGenArgs a) {
         const Uniform2 up = uniform2(a.seed, e, ep, SG_POLY_POS, q);
         const Uniform2 um = uniform2(a.seed, e, ep, SG_POLY_MOTION, q);
         const Uniform2 uw = uniform2(a.seed, e, ep, SG_POLY_WIDTH, q);
-        const double w = a.w_lo + (a.w_hi - a.w_lo) * uw.a;
-        const double spd = a.s_lo + (a.s_hi - a.s_lo) * um.b;
+        const double w = draw_size(a.w_lo, a.w_hi, uw, a.size_law);
+        double spd = a.s_lo + (a.s_hi - a.s_lo) * um.b;
+        if (a.size_law) {
+            const Uniform2 us = uniform2(a.seed, e, ep, SG_POLY_SPEED, q);
+            spd = a.s_lo + (a.s_hi - a.s_lo) * ((us.a + us.b) * 0.5);
+        }
         const double h = um.a * kTwoPi - kPi;
         double X = up.a * (2.0 * E) - E;
         double Y = up.b * (2.0 * E) - E;

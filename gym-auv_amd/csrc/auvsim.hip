@@ -272,6 +272,7 @@ int launch_scenegen(auv_sim* h, hipStream_t st, const uint8_t* only_done) {
     ga.s_hi = p.s_hi;
     ga.clearance = p.clearance;
     ga.path_length = p.path_length;
+    ga.size_law = p.size_law;
     const long long work = (long long)d.V * (1 + d.C + d.P);
     hipLaunchKernelGGL(k_scenegen, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, ga);
     HIP_TRY(h, hipGetLastError());
@@ -586,7 +587,7 @@ int do_step(auv_sim* h, const double* action_dev, hipStream_t st) {
 
 extern "C" {
 
-const char* auv_version(void) { return "libauvsim abi 1 gfx950 fp64-unfused"; }
+const char* auv_version(void) { return "libauvsim abi 2 gfx950 fp64-unfused"; }
 
 const char* auv_last_error(auv_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -815,10 +816,11 @@ int auv_generate_scene(auv_handle h, uint64_t seed, const auv_scene_params* para
     if (!h) return AUV_ERR_ARG;
     const Dims& d = h->d;
     if (d.P > 0 && d.NV < 5) return fail(h, AUV_ERR_ARG, "auv_generate_scene: ships need n_verts >= 5, batch has %d", d.NV);
-    auv_scene_params p = {200.0, 5.0, 30.0, 5.0, 20.0, 0.3, 1.2, 25.0, 800.0};
+    auv_scene_params p = {200.0, 5.0, 30.0, 5.0, 20.0, 0.3, 1.2, 25.0, 800.0, AUV_SIZES_UNIFORM, 0};
     if (params) p = *params;
     if (!(p.extent > 0.0) || !(p.r_lo > 0.0) || !(p.r_hi >= p.r_lo) || !(p.w_lo > 0.0) || !(p.w_hi >= p.w_lo) ||
-        !(p.s_lo >= 0.0) || !(p.s_hi >= p.s_lo) || !(p.clearance >= 0.0) || !(p.path_length > 0.0))
+        !(p.s_lo >= 0.0) || !(p.s_hi >= p.s_lo) || !(p.clearance >= 0.0) || !(p.path_length > 0.0) ||
+        (p.size_law != AUV_SIZES_UNIFORM && p.size_law != AUV_SIZES_BELL))
         return fail(h, AUV_ERR_ARG, "auv_generate_scene: parameters out of range");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = pick(h, stream);

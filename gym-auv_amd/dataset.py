@@ -9,8 +9,10 @@ logged sample, the three files row-aligned:
   metadata_<name>.csv  speed_OS heading_OS then (heading_ts dist speed bearing
                        course) per tracked obstacle   (utils/explore_dataset.py:8,40-53)
 A sample is logged only when at least one obstacle is tracked (every shipped
-row has one); an obstacle is tracked when its slot is in use and its hull
-distance is below the sensor range.
+row has one).  Which obstacles a row lists follows the rule the shipped rows
+show (`update_tracked`): the list is rebuilt every 25 steps of an episode from
+the obstacles whose logged distance is below the sensor range, and kept as it
+is in between -- which is why the shipped rows hold obstacles out to 176 m.
 """
 from __future__ import annotations
 
@@ -92,23 +94,48 @@ class DatasetWriter:
         self.close()
 
 
-class DatasetLogger:
-    """Logs every `every`-th step of an `AuvSim` (the shipped rows are about
-    5 s of simulated time apart)."""
+def update_tracked(tracked, t_step, present, dist, sensor_range=SENSOR_RANGE, refresh_every=25):
+    """The obstacle list of every env after one more step.
 
-    def __init__(self, sim, writer: DatasetWriter, every: int = 5):
-        self.sim, self.writer, self.every = sim, writer, int(every)
-        self._k = 0
+    The reference's rows (data/metadata_MovingObstaclesNoRules.csv) change their
+    obstacle lists almost only at every fifth logged row, i.e. every 25 steps:
+    at those steps every obstacle whose logged `dist` is below the sensor range
+    is listed (an obstacle never enters a list at 150 m or more: the largest
+    `dist` in a row whose list has just changed is 149.93 m), and until the
+    next rebuild the list stays as it is, so that obstacles sailing away remain
+    listed out to 176 m.  tracked: bool [V,O] lists so far (None: build them
+    now); t_step [V]: steps into the episode; present: bool [V,O] slot in use;
+    dist [V,O]: the logged distance column."""
+    fresh = present & (dist < sensor_range)
+    if tracked is None:
+        return fresh
+    rebuild = (np.asarray(t_step) % int(refresh_every)) == 0
+    return np.where(rebuild[:, None], fresh, tracked & present)
+
+
+class DatasetLogger:
+    """Logs the envs of an `AuvSim` whose episode is at a multiple of `every`
+    steps (the shipped rows are 5 steps = 5 s of simulated time apart), with
+    the obstacle lists kept by `update_tracked`."""
+
+    def __init__(self, sim, writer: DatasetWriter, every: int = 5, refresh_every: int = 25):
+        self.sim, self.writer, self.every, self.refresh_every = sim, writer, int(every), int(refresh_every)
+        self._tracked = None
 
     def after_step(self, stream=None):
-        self._k += 1
-        if self._k % self.every:
-            return 0
         sim = self.sim
-        dist = sim.read("obst_dist", stream, pinned=True)
-        tracked = np.isfinite(dist) & (dist < sim.cfg["sensor_range"])
+        t = sim.read("t_step", stream, pinned=True)
+        due = (t % self.every) == 0
+        if not due.any():
+            return 0
+        # the lists only change at multiples of refresh_every, which `every` divides: looking at logging steps is enough
+        meta = sim.read("meta", stream, pinned=True)
+        present = np.isfinite(sim.read("obst_dist", stream, pinned=True))
+        self._tracked = update_tracked(self._tracked, t, present, meta[:, :, 1], sim.cfg["sensor_range"],
+                                       self.refresh_every)
+        tracked = self._tracked & due[:, None]
         return self.writer.write(sim.read("ranges", stream, pinned=True), sim.read("own", stream, pinned=True),
-                                 sim.read("meta", stream, pinned=True), sim.read("risk", stream, pinned=True), tracked)
+                                 meta, sim.read("risk", stream, pinned=True), tracked)
 
 
 def save_binary(path, ranges, own, meta, risk, tracked):

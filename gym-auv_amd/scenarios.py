@@ -105,6 +105,14 @@ def make_scene(V, C, P, NV=5, seed=0, extent=200.0, n_sides=None, moving=True,
     }
 
 
+# Generator parameters that follow what the reference's logged rows show of its scenario
+# (data/metadata_MovingObstaclesNoRules.csv; sizes and speeds recovered by tests/golden/make_scan_golden.py):
+# whole-number circle radii 15..41 m and ship sizes 1..18 m with bell-shaped laws, ship speeds up to ~0.9 m/s
+# peaking near 0.5, and an obstacle density that lists 2-3 obstacles within the 150 m sensor range on average
+# (16 obstacles over an 850 m square).
+REFERENCE_LIKE = dict(extent=425.0, r_lo=15.0, r_hi=41.0, w_lo=1.0, w_hi=18.0, s_lo=0.05, s_hi=0.9, clearance=25.0,
+                      path_length=800.0, size_law=1)
+
 # the five benchmark configurations: vessels, rays, scene, seed
 WORKLOADS = {
     "cfg1_single_episode": dict(V=1, R=180, C=17, P=17, NV=5, seed=0, extent=400.0),

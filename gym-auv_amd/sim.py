@@ -121,16 +121,18 @@ class AuvSim:
         """Scene, paths and initial states of every env from the device-side
         generator (episode 0); follow with `reset(None)`.  `params` overrides
         the defaults by name (extent, r_lo, r_hi, w_lo, w_hi, s_lo, s_hi,
-        clearance, path_length)."""
+        clearance, path_length, size_law; `scenarios.REFERENCE_LIKE` is the set that
+        follows the sizes and speeds of the reference's logged rows)."""
         p = None
         if params is not None:
             full = dict(extent=200.0, r_lo=5.0, r_hi=30.0, w_lo=5.0, w_hi=20.0, s_lo=0.3, s_hi=1.2,
-                        clearance=25.0, path_length=800.0)
+                        clearance=25.0, path_length=800.0, size_law=0)
             unknown = set(params) - set(full)
             if unknown:
                 raise ValueError(f"unknown generator parameters {sorted(unknown)}")
             full.update(params)
-            p = C.byref(_lib.AuvSceneParams(**{k: float(v) for k, v in full.items()}))
+            law = int(full.pop("size_law"))
+            p = C.byref(_lib.AuvSceneParams(size_law=law, reserved=0, **{k: float(v) for k, v in full.items()}))
         self._check(self._lib.auv_generate_scene(self._h, int(seed) & (2 ** 64 - 1), p, _stream_handle(stream)))
 
     def reset(self, init_state, mask=None, stream=None):

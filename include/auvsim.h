@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define AUVSIM_ABI_VERSION 1
+#define AUVSIM_ABI_VERSION 2   /* 2: auv_scene_params.size_law */
 #define AUV_N_MODEL 16
 #define AUV_NAV_FEATURES 6   /* radarCNN.py:185 */
 #define AUV_META_FIELDS 5    /* utils/explore_dataset.py:45 */
@@ -191,14 +191,23 @@ typedef struct auv_scene_params {
     double s_lo, s_hi;   /* ship speed ~ U, heading ~ U(-pi, pi) */
     double clearance;    /* no hull starts nearer than this to the vessel */
     double path_length;  /* straight path from the origin along the vessel's initial heading */
+    int32_t size_law;    /* AUV_SIZES_UNIFORM (0): radius, beam and speed uniform over [lo, hi].
+                            AUV_SIZES_BELL (1): radius and beam are whole numbers lo..hi with a triangular law
+                            (floor of lo + (hi + 1 - lo)(u + u')/2), speed triangular over [lo, hi]: the shape of
+                            the sizes and speeds recovered from the reference's logged rows (whole radii 15..41 m
+                            peaking near 29, whole ship sizes 1..18 m peaking near 8, speeds 0.06..1.2 m/s
+                            peaking near 0.5) */
+    int32_t reserved;
 } auv_scene_params;
+#define AUV_SIZES_UNIFORM 0
+#define AUV_SIZES_BELL 1
 
 /* Generate scene, paths and initial states of EVERY env on the device, for
  * episode 0 (clears AUV_BUF_EPISODE): `n_circles` static circles and `n_polys`
  * five-vertex ships per env (needs n_verts >= 5 when n_polys > 0), each number
  * a function of (seed, env, episode, purpose, index) through Philox4x32-10.
  * params == NULL: extent 200, radius 5..30, beam 5..20, speed 0.3..1.2,
- * clearance 25, path 800.  Afterwards auv_reset may be called with
+ * clearance 25, path 800, uniform sizes.  Afterwards auv_reset may be called with
  * init_state == NULL.  Replaces the scenario constructor of the env
  * (MovingObstaclesNoRules, the scenario named by the reference's data files
  * data/ *_MovingObstaclesNoRules.csv).  Asynchronous on `stream`. */

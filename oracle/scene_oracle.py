@@ -25,10 +25,10 @@ W0, W1 = 0x9E3779B9, 0xBB67AE85
 MASK32 = np.uint64(0xFFFFFFFF)
 
 # purposes (third counter word)
-K_VESSEL, K_CIRCLE_POS, K_CIRCLE_RAD, K_POLY_POS, K_POLY_MOTION, K_POLY_WIDTH = range(6)
+K_VESSEL, K_CIRCLE_POS, K_CIRCLE_RAD, K_POLY_POS, K_POLY_MOTION, K_POLY_WIDTH, K_POLY_SPEED = range(7)
 
 DEFAULT_PARAMS = dict(extent=200.0, r_lo=5.0, r_hi=30.0, w_lo=5.0, w_hi=20.0, s_lo=0.3, s_hi=1.2,
-                      clearance=25.0, path_length=800.0)
+                      clearance=25.0, path_length=800.0, size_law=0)
 PARAM_ORDER = ("extent", "r_lo", "r_hi", "w_lo", "w_hi", "s_lo", "s_hi", "clearance", "path_length")
 
 
@@ -64,6 +64,13 @@ def _push_out(x, y, clear):
     return x * f, y * f
 
 
+def _draw_size(lo, hi, ua, ub, bell):
+    """A size in [lo, hi]: uniform from ua, or (bell) a whole number lo..hi from the mean of two uniforms."""
+    if bell:
+        return np.floor(lo + ((hi + 1.0) - lo) * ((ua + ub) * 0.5))
+    return lo + (hi - lo) * ua
+
+
 def generate(seed, envs, episodes, C, P, NV, params=None):
     """Scene arrays of the given envs (1-D int arrays `envs`, `episodes`), laid
     out as gym_auv_amd.scenarios documents them."""
@@ -85,8 +92,8 @@ def generate(seed, envs, episodes, C, P, NV, params=None):
         e2, p2 = envs[:, None], ep[:, None]
         j = np.broadcast_to(np.arange(C), (n, C))
         ux, uy = uniform2(seed, e2, p2, K_CIRCLE_POS, j)
-        ur, _ = uniform2(seed, e2, p2, K_CIRCLE_RAD, j)
-        rad = p["r_lo"] + (p["r_hi"] - p["r_lo"]) * ur
+        ur, ur2 = uniform2(seed, e2, p2, K_CIRCLE_RAD, j)
+        rad = _draw_size(p["r_lo"], p["r_hi"], ur, ur2, p["size_law"])
         cx, cy = _push_out(ux * (2.0 * E) - E, uy * (2.0 * E) - E, rad + p["clearance"])
         circles[..., 0], circles[..., 1], circles[..., 2] = cx, cy, rad
     pose = np.zeros((n, P, 6))
@@ -100,9 +107,12 @@ def generate(seed, envs, episodes, C, P, NV, params=None):
         q = np.broadcast_to(np.arange(P), (n, P))
         ux, uy = uniform2(seed, e2, p2, K_POLY_POS, q)
         uh, us = uniform2(seed, e2, p2, K_POLY_MOTION, q)
-        uw, _ = uniform2(seed, e2, p2, K_POLY_WIDTH, q)
-        w = p["w_lo"] + (p["w_hi"] - p["w_lo"]) * uw
+        uw, uw2 = uniform2(seed, e2, p2, K_POLY_WIDTH, q)
+        w = _draw_size(p["w_lo"], p["w_hi"], uw, uw2, p["size_law"])
         spd = p["s_lo"] + (p["s_hi"] - p["s_lo"]) * us
+        if p["size_law"]:
+            us1, us2 = uniform2(seed, e2, p2, K_POLY_SPEED, q)
+            spd = p["s_lo"] + (p["s_hi"] - p["s_lo"]) * ((us1 + us2) * 0.5)
         h = uh * TWO_PI - PI
         X, Y = _push_out(ux * (2.0 * E) - E, uy * (2.0 * E) - E, 2.0 * w + p["clearance"])
         sh, ch = sincos(h)

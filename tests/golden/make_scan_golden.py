@@ -30,7 +30,9 @@ all have a recovered size: heading_ts, dist, bearing, integer size, class; per
 row: its index in the file, heading_OS, and the label the reference trains
 against (row-wise max of data/risk_*.csv, utils/dataloader.py:113-114); and the
 mean and standard deviation of the test errors the reference publishes for its
-three networks (results_RL/_mse_1conv.txt, _mse_3conv.txt, _mse_deep.txt).
+three networks (results_RL/_mse_1conv.txt, _mse_3conv.txt, _mse_deep.txt); and
+the bucket counts of the whole file as utils/explore_dataset.py:40-53 tallies
+them (static / dynamic x distance, risk, relative speed; obstacles per row).
 """
 import os
 import sys
@@ -298,13 +300,25 @@ def main():
     # the test errors the reference publishes for its three networks (results_RL/_mse_*.txt, 100 values each)
     pub = [np.loadtxt(os.path.join(ref, "results_RL", f"_mse_{k}.txt")) for k in ("1conv", "3conv", "deep")]
     print("published test MSE (shallow, 2_deep, deep): mean", [float(p.mean()) for p in pub], "std", [float(p.std()) for p in pub])
+    # the reference's own summary of its dataset (the buckets of utils/explore_dataset.py:40-53), over every record
+    recs = np.concatenate(log.recs)
+    own_speed = np.concatenate([np.full(len(R), log.speed[i]) for i, R in enumerate(log.recs)])
+    risk_all = np.concatenate(log.risk)
+    st_all = np.concatenate(log.static)
+    buckets = {}
+    for name, m in (("static", st_all), ("dynamic", ~st_all)):
+        buckets[f"bucket_{name}_dist"] = np.histogram(recs[m, 1], bins=[-1e9, 50.0, 100.0, 1e9])[0]
+        buckets[f"bucket_{name}_risk"] = np.histogram(risk_all[m], bins=[-1.0, 0.2, 0.4, 0.6, 0.8, 1.01])[0]
+        buckets[f"bucket_{name}_speed"] = np.histogram(recs[m, 2], bins=[-1.0, 0.5, 1.0, 1.5, 1e9])[0]
+    buckets["bucket_count"] = np.bincount([len(R) for R in log.recs], minlength=9)
+    print("bucket table:", {k: v.tolist() for k, v in buckets.items()})
     dst = os.path.join(HERE, "scan_golden.npz")
     np.savez_compressed(dst, row=np.array(row, dtype=np.int32), heading_os=np.array(psi), label=np.array(label),
                         first=np.array(first, dtype=np.int32), heading_ts=np.array(cols["heading_ts"]),
                         dist=np.array(cols["dist"]), bearing=np.array(cols["bearing"]),
                         size=size.astype(np.int8), static=st, n_rows_file=np.int32(log.n),
                         published_mse_mean=np.array([p.mean() for p in pub]),
-                        published_mse_std=np.array([p.std() for p in pub]))
+                        published_mse_std=np.array([p.std() for p in pub]), **buckets)
     print("wrote", dst, os.path.getsize(dst), "bytes")
 
 

@@ -149,7 +149,10 @@ def test_dataset_logger_writes_the_oracles_rows(tmp_path):
         env.step(acts[k])
         rows += logger.after_step()
         if (k + 1) % 5 == 0:
-            tracked = np.isfinite(env.obst_dist) & (env.obst_dist < cfg["sensor_range"])
+            # no step of this rollout is a multiple of 25: the lists are those of the first logged step
+            if k + 1 == 5:
+                tracked = np.isfinite(env.obst_dist) & (env.meta[:, :, 1] < cfg["sensor_range"])
+            tracked = tracked & np.isfinite(env.obst_dist)
             wo.write(env.ranges, env.own, env.meta, env.risk, tracked)
     wd.close()
     wo.close()
@@ -178,6 +181,65 @@ def test_dataset_logger_writes_the_oracles_rows(tmp_path):
         n_static += int(st.sum())
         n_moving += int((~st).sum())
     assert n_static > 100 and n_moving > 100
+    sim.close()
+
+
+def test_regenerated_dataset_resembles_the_reference_file(tmp_path):
+    """Scenes from the generator with the sizes and speeds of the reference's logged rows, listed by the
+    reference's rule, logged every 5 steps: the bucket table of utils/explore_dataset.py:40-53 over the regenerated
+    metadata / risk files must resemble the reference file's (tests/golden/scan_golden.npz holds its counts).
+    Tolerances are absolute differences of bucket fractions; the vessel here is steered at random, the
+    reference's by a trained agent, so only the coarse shape is comparable."""
+    import torch
+
+    from gym_auv_amd import dataset as D
+    from gym_auv_amd import params
+    from gym_auv_amd.sim import AuvSim
+
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "scan_golden.npz"))
+    V = 600
+    cfg = params.make_config(V, 8, 8, 5, max_steps=400)
+    sim = AuvSim(cfg)
+    sim.generate_scene(2026, scenarios.REFERENCE_LIKE)
+    sim.set_option(_lib.OPT_AUTO_RESET, 1)
+    sim.set_option(_lib.OPT_REGENERATE, 1)
+    sim.reset(None)
+    w = D.DatasetWriter(str(tmp_path))
+    logger = D.DatasetLogger(sim, w)
+    rng = np.random.default_rng(6)
+    act = np.zeros((2, V))
+    for k in range(150):
+        if k % 10 == 0:   # a helmsman who holds a command for a while: mostly ahead at 60-100 % thrust
+            act[0], act[1] = rng.uniform(0.6, 1.0, V), rng.uniform(-0.3, 0.3, V)
+        sim.step_host(act)
+        logger.after_step()
+    w.close()
+    meta, risk = D.read_ragged(w.paths["metadata"]), D.read_ragged(w.paths["risk"])
+    assert len(meta) == len(risk) == w.rows > 5000
+    table = {k: np.zeros_like(ref[k]) for k in ref.files if k.startswith("bucket_")}
+    far = 0.0
+    for m, r in zip(meta, risk):
+        speed_os, _, rec = D.parse_metadata_row(m)
+        table["bucket_count"][min(len(rec), 8)] += 1
+        far = max(far, rec[:, 1].max())
+        for x, rk in zip(rec, r):
+            name = "static" if D.is_static(x, speed_os) else "dynamic"
+            table[f"bucket_{name}_dist"][np.searchsorted([50.0, 100.0], x[1], side="right")] += 1
+            table[f"bucket_{name}_risk"][min(int(rk / 0.2), 4)] += 1
+            table[f"bucket_{name}_speed"][min(int(x[2] / 0.5), 3)] += 1
+    assert far > 150.0 + 1.0      # lists have memory: obstacles stay listed beyond the sensor range, as in the reference
+    frac = lambda a: a / a.sum()
+    n_static = table["bucket_static_dist"].sum()
+    n_dynamic = table["bucket_dynamic_dist"].sum()
+    ref_static = ref["bucket_static_dist"].sum() / (ref["bucket_static_dist"].sum() + ref["bucket_dynamic_dist"].sum())
+    assert abs(n_static / (n_static + n_dynamic) - ref_static) < 0.15
+    report = {}
+    for k, tol in (("bucket_static_dist", 0.15), ("bucket_dynamic_dist", 0.15), ("bucket_static_risk", 0.15),
+                   ("bucket_dynamic_risk", 0.2), ("bucket_static_speed", 0.3), ("bucket_count", 0.15)):
+        d = np.abs(frac(table[k]) - frac(ref[k])).max()
+        report[k] = (np.round(frac(table[k]), 3).tolist(), np.round(frac(ref[k]), 3).tolist())
+        assert d < tol, (k, report[k])
+    print("regenerated vs reference bucket fractions:", report)
     sim.close()
 
 

@@ -133,3 +133,39 @@ def test_native_formatter_under_sanitizers(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
     run = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
     assert run.returncode == 0 and run.stdout.startswith("ok"), run.stdout + run.stderr
+
+
+def test_obstacle_lists_are_rebuilt_every_25_steps_and_kept_in_between():
+    from gym_auv_amd.dataset import update_tracked
+
+    present = np.array([[True, True, False], [True, True, True]])
+    dist = np.array([[10.0, 160.0, 5.0], [149.9, 150.0, -2.0]])
+    tr = update_tracked(None, np.array([0, 0]), present, dist)
+    assert tr.tolist() == [[True, False, False], [True, False, True]]
+    # five steps on: env 0's first obstacle has sailed out of range and its second into range: nothing changes yet
+    dist2 = np.array([[170.0, 120.0, 5.0], [149.9, 100.0, -2.0]])
+    tr2 = update_tracked(tr, np.array([5, 5]), present, dist2)
+    assert tr2.tolist() == tr.tolist()
+    # step 25 of env 0 (env 1 restarted 3 steps ago and is not at a rebuild)
+    tr3 = update_tracked(tr2, np.array([25, 3]), present, dist2)
+    assert tr3.tolist() == [[False, True, False], [True, False, True]]
+    # an emptied slot leaves the list at once
+    gone = present.copy()
+    gone[1, 2] = False
+    assert update_tracked(tr3, np.array([30, 8]), gone, dist2).tolist() == [[False, True, False], [True, False, False]]
+
+
+def test_shipped_rows_follow_the_listing_rule():
+    """In the rows the reference shipped, a row whose obstacle list differs from the previous row's lists no
+    obstacle at or beyond the sensor range, while other rows do (obstacles kept on the list while sailing away)."""
+    rows = [np.array(line.split(), dtype=np.float64) for line in open(os.path.join(G, "metadata_rows.csv"))]
+    changed_max, kept_max, prev = 0.0, 0.0, None
+    for r in rows:
+        rec = r[2:].reshape(-1, 5)
+        key = (len(rec), tuple(np.round(rec[:, 0], 9)))
+        if prev is not None and key != prev:
+            changed_max = max(changed_max, rec[:, 1].max())
+        else:
+            kept_max = max(kept_max, rec[:, 1].max())
+        prev = key
+    assert changed_max < 150.0 < kept_max

@@ -170,6 +170,18 @@ def test_generated_scenes_and_regeneration_match_oracle():
     sim.reset(None)
     env.reset(None)
     assert_all_equal(sim, env, "default parameters")
+    # the size law of the reference's logged scenes: whole-number radii and ship sizes, bell-shaped
+    sim.generate_scene(11, scenarios.REFERENCE_LIKE)
+    env.generate_scene(11, scenarios.REFERENCE_LIKE)
+    sim.reset(None)
+    env.reset(None)
+    assert_all_equal(sim, env, "reference-like parameters")
+    rad = sim.read("circles")[:, :, 2]
+    assert np.array_equal(rad, np.rint(rad)) and rad.min() >= 15 and rad.max() <= 41
+    for k in range(3):
+        sim.step_host(acts[k])
+        env.step(acts[k])
+    assert_all_equal(sim, env, "reference-like parameters, stepped and restarted")
     sim.close()
     # ships need five vertex slots
     sim = AuvSim(params.make_config(4, 1, 1, 4))
