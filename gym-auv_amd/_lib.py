@@ -41,6 +41,8 @@ LIDAR_RASTER, LIDAR_ALL_PAIRS = 0, 1
 RISK_CPA, RISK_REFERENCE = 0, 1
 STATS_FIELDS = 8
 SIZES_UNIFORM, SIZES_BELL = 0, 1
+OPT_ADAMW, OPT_SGD_MOMENTUM = 0, 1
+TRAIN_BATCH_MAX = 16
 STATS_MAX_ENVS = 1048576
 
 # CNN consumers
@@ -55,7 +57,7 @@ EXPORTS = (
     "auv_profile_enable", "auv_cnn_n_weights", "auv_cnn_out_dim", "auv_cnn_create", "auv_cnn_destroy",
     "auv_cnn_forward", "auv_cnn_last_error", "auv_format_rows",
     "auv_profile_read", "auv_attach_cnn", "auv_generate_scene", "auv_host_alloc", "auv_host_free",
-    "auv_risk_rows", "auv_episode_stats", "auv_episode_stats_static",
+    "auv_risk_rows", "auv_episode_stats", "auv_episode_stats_static", "auv_train_shallow",
 )
 
 
@@ -74,6 +76,11 @@ class AuvConfig(C.Structure):
 class AuvSceneParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("extent", "r_lo", "r_hi", "w_lo", "w_hi", "s_lo", "s_hi", "clearance",
                                           "path_length")] + [("size_law", C.c_int32), ("reserved", C.c_int32)]
+
+
+class AuvTrainParams(C.Structure):
+    _fields_ = [("optimizer", C.c_int32), ("reserved", C.c_int32), ("lr", C.c_double), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double), ("momentum", C.c_double)]
 
 
 class AuvError(RuntimeError):
@@ -167,5 +174,7 @@ def load():
     lib.auv_episode_stats.argtypes = [vp, vp, i32, vp]
     lib.auv_episode_stats_static.restype = C.c_int
     lib.auv_episode_stats_static.argtypes = [vp, vp, i32, vp]
+    lib.auv_train_shallow.restype = C.c_int
+    lib.auv_train_shallow.argtypes = [C.c_int, vp, vp, i64, vp, i64, i32, vp, vp, C.POINTER(AuvTrainParams), i64, vp, vp]
     _lib = lib
     return lib

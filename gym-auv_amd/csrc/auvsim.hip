@@ -22,6 +22,7 @@
 #include "auv_scenegen.hpp"
 #include "auv_format.hpp"
 #include "auv_stats.hpp"
+#include "auv_train.hpp"
 
 using namespace auv;
 
@@ -1262,6 +1263,46 @@ int auv_cnn_forward(auv_cnn_handle c, const float* scans, int64_t n_scans, int32
         hipLaunchKernelGGL(k_cnn, dim3(blocks), dim3(256), cnn_lds_bytes(a.kind), (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cnn_fail(c, AUV_ERR_DEVICE, "k_cnn launch failed: %s", hipGetErrorString(e));
+    return AUV_OK;
+}
+
+int auv_train_shallow(int device, const float* X, const float* y, int64_t n_rows, const int32_t* perm,
+                      int64_t n_batches, int32_t batch, float* weights, float* opt_state,
+                      const auv_train_params* hp, int64_t steps_done, float* batch_loss, void* stream) {
+    if (!X || !y || !perm || !weights || !opt_state || !hp || !batch_loss)
+        return cnn_fail(nullptr, AUV_ERR_ARG, "auv_train_shallow: null argument");
+    if (batch < 1 || batch > AUV_TRAIN_BATCH_MAX)
+        return cnn_fail(nullptr, AUV_ERR_ARG, "auv_train_shallow: batch must be in 1..%d, got %d", AUV_TRAIN_BATCH_MAX, batch);
+    if (n_rows < 1 || n_batches < 0 || steps_done < 0)
+        return cnn_fail(nullptr, AUV_ERR_ARG, "auv_train_shallow: n_rows must be >= 1, n_batches and steps_done >= 0");
+    if (hp->optimizer != AUV_OPT_ADAMW && hp->optimizer != AUV_OPT_SGD_MOMENTUM)
+        return cnn_fail(nullptr, AUV_ERR_ARG, "auv_train_shallow: unknown optimizer %d", hp->optimizer);
+    if (!(hp->lr > 0.0)) return cnn_fail(nullptr, AUV_ERR_ARG, "auv_train_shallow: lr must be positive");
+    if (n_batches == 0) return AUV_OK;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+        return cnn_fail(nullptr, AUV_ERR_DEVICE, "auv_train_shallow: no HIP device %d", device);
+    if (hipSetDevice(device) != hipSuccess) return cnn_fail(nullptr, AUV_ERR_DEVICE, "hipSetDevice failed");
+    TrainArgs a;
+    a.X = X;
+    a.y = y;
+    a.perm = perm;
+    a.n_batches = n_batches;
+    a.batch = batch;
+    a.optimizer = hp->optimizer;
+    a.step0 = steps_done;
+    a.w = weights;
+    a.opt = opt_state;
+    a.batch_loss = batch_loss;
+    a.lr = hp->lr;
+    a.beta1 = hp->beta1;
+    a.beta2 = hp->beta2;
+    a.eps = hp->eps;
+    a.weight_decay = hp->weight_decay;
+    a.momentum = hp->momentum;
+    hipLaunchKernelGGL(k_train_shallow, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cnn_fail(nullptr, AUV_ERR_DEVICE, "k_train_shallow launch failed: %s", hipGetErrorString(e));
     return AUV_OK;
 }
 

@@ -47,6 +47,104 @@ class Trainer:
         return self.training_loss, self.validation_loss
 
 
+class DeviceTrainer:
+    """`Trainer` for the one-convolution network with the data resident on the
+    GPU: every epoch's batches (trainer.py:80-83) run in one launch of the
+    library's fused training kernel (`auv_train_shallow`: forward, MSE,
+    backward and the optimizer step of trainer.py:44-53 per batch, parameters
+    and optimizer state on chip), instead of ~10 small launches per batch.
+
+    X_* float32 [n,1,180] or [n,180] closeness scans and y_* float32 [n] or
+    [n,1] labels, numpy or torch (copied to the device once).  `model` is a
+    `models.LidarCNNShallow`; its parameters are read at construction and
+    written back after every epoch, so `model.state_dict()` feeds
+    `cnn.LidarCNN` (the HIP inference path) as before."""
+
+    def __init__(self, model, epochs: int, learning_rate: float, X_train, y_train, X_val=None, y_val=None,
+                 optimizer: str = "adamw", batch_size: int = 16, seed: int = 2, device: int = 0):
+        import ctypes as C
+
+        from . import _lib
+        from .cnn import STATE_KEYS, pack_weights
+
+        self._lib, self._C, self._api = _lib.load(), C, _lib
+        if not 1 <= batch_size <= _lib.TRAIN_BATCH_MAX:
+            raise ValueError(f"batch_size must be in 1..{_lib.TRAIN_BATCH_MAX}")
+        self.model, self.epochs, self.device = model, int(epochs), int(device)
+        self.batch_size = int(batch_size)
+        dev = torch.device("cuda", self.device)
+        as_dev = lambda t, shape: torch.as_tensor(np.asarray(t) if not torch.is_tensor(t) else t, dtype=torch.float32) \
+            .reshape(shape).contiguous().to(dev)
+        self.X, self.y = as_dev(X_train, (-1, 180)), as_dev(y_train, (-1,))
+        self.Xv = None if X_val is None else as_dev(X_val, (-1, 180))
+        self.yv = None if y_val is None else as_dev(y_val, (-1,))
+        if len(self.X) != len(self.y):
+            raise ValueError("X_train and y_train differ in length")
+        self._keys = STATE_KEYS["shallow"]
+        self.w = torch.from_numpy(pack_weights("shallow", model.state_dict())).to(dev)
+        self.opt_state = torch.zeros(2 * self.w.numel(), dtype=torch.float32, device=dev)
+        self.hp = _lib.AuvTrainParams(optimizer=_lib.OPT_SGD_MOMENTUM if optimizer == "sgd" else _lib.OPT_ADAMW,
+                                      reserved=0, lr=float(learning_rate), beta1=0.9, beta2=0.999, eps=1e-8,
+                                      weight_decay=0.01, momentum=0.9)
+        self.steps_done = 0
+        self._gen = torch.Generator().manual_seed(int(seed))
+        self.training_loss, self.validation_loss = [], []
+
+    def train_epoch(self, perm=None):
+        """One pass over the training rows in batches (drop_last); `perm`: the row
+        order (default: a fresh shuffle).  Returns the per-batch losses (device tensor)."""
+        C = self._C
+        n = len(self.X)
+        if perm is None:
+            perm = torch.randperm(n, generator=self._gen)
+        n_batches = n // self.batch_size
+        perm_d = torch.as_tensor(perm, dtype=torch.int32)[:n_batches * self.batch_size].contiguous().to(self.X.device)
+        losses = torch.empty(n_batches, dtype=torch.float32, device=self.X.device)
+        st = torch.cuda.current_stream(self.X.device).cuda_stream
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = self._lib.auv_train_shallow(self.device, p(self.X), p(self.y), n, p(perm_d), n_batches, self.batch_size,
+                                         p(self.w), p(self.opt_state), C.byref(self.hp), self.steps_done, p(losses),
+                                         C.c_void_p(st))
+        if rc != 0:
+            raise self._api.AuvError(rc, self._lib.auv_cnn_last_error(None).decode())
+        self.steps_done += n_batches
+        return losses
+
+    def sync_model(self):
+        """Write the trained parameters back into `model`."""
+        flat = self.w.detach().cpu()
+        sd, o = {}, 0
+        ref = self.model.state_dict()
+        for k in self._keys:
+            n = ref[k].numel()
+            sd[k] = flat[o:o + n].reshape(ref[k].shape).clone()
+            o += n
+        self.model.load_state_dict(sd)
+        return self.model
+
+    @torch.no_grad()
+    def validation_step(self):
+        if self.Xv is None:
+            return float("nan")
+        from .cnn import LidarCNN
+
+        net = LidarCNN("shallow", self.sync_model().state_dict(), device=self.device)
+        pred = net.forward(self.Xv.reshape(-1, 1, 180), "risk")[:, 0]
+        net.close()
+        # the reference averages the losses of the validation batches (trainer.py:55-69)
+        b = self.batch_size
+        per = (pred - self.yv) ** 2
+        means = [per[i:i + b].mean() for i in range(0, len(per), b)]
+        return float(torch.stack(means).mean().item())
+
+    def train(self):
+        for _ in range(self.epochs):
+            self.training_loss.append(float(self.train_epoch().mean().item()))
+            self.validation_loss.append(self.validation_step())
+        self.sync_model()
+        return self.training_loss, self.validation_loss
+
+
 def batches(X: np.ndarray, y: np.ndarray, batch_size: int = 16, shuffle: bool = True, drop_last: bool = True,
             seed: int = 2):
     """Mini-batches of a split from `dataset.load_lidar_dataset` (batch 16,

@@ -346,6 +346,35 @@ int auv_cnn_forward(auv_cnn_handle c, const float* scans, int64_t n_scans, int32
                     void* stream);
 const char* auv_cnn_last_error(auv_cnn_handle c);
 
+/* ---- training the one-convolution network on the device ---------------------
+ * Trainer.train_batch (trainer.py:44-53: forward, MSE loss, backward, optimizer
+ * step, zero_grad) over every batch of an epoch (trainer.py:80-83) in ONE
+ * launch, for LidarCNN_shallow (models/lidar_cnn_shallow.py:23-52).  All
+ * pointers but `hp` are DEVICE memory on `device`:
+ *   X [n_rows,180] f32 scans (closeness), y [n_rows] f32 labels,
+ *   perm [n_batches*batch] i32 row index of every slot of every batch (the
+ *   DataLoader's shuffle, utils/dataloader.py:76-80; batch <= 16),
+ *   weights [59] f32 in/out (state-dict order, as auv_cnn_create takes them),
+ *   opt_state [118] f32 in/out (AdamW: exp_avg, exp_avg_sq; SGD: momentum
+ *   buffer; zeros before the first step), batch_loss [n_batches] f32 out (what
+ *   train_batch returns per batch).  steps_done = optimizer steps before this
+ *   call (AdamW's bias correction).  The update formulas are torch.optim's
+ *   (AdamW: trainer.py:33, SGD momentum: trainer.py:35).  Asynchronous on
+ *   `stream`. */
+typedef struct auv_train_params {
+    int32_t optimizer;     /* AUV_OPT_ADAMW | AUV_OPT_SGD_MOMENTUM */
+    int32_t reserved;
+    double lr;
+    double beta1, beta2, eps, weight_decay;  /* AdamW (torch defaults 0.9, 0.999, 1e-8, 0.01) */
+    double momentum;                         /* SGD (trainer.py:35: 0.9) */
+} auv_train_params;
+#define AUV_OPT_ADAMW 0
+#define AUV_OPT_SGD_MOMENTUM 1
+#define AUV_TRAIN_BATCH_MAX 16
+int auv_train_shallow(int device, const float* X, const float* y, int64_t n_rows, const int32_t* perm,
+                      int64_t n_batches, int32_t batch, float* weights, float* opt_state,
+                      const auv_train_params* hp, int64_t steps_done, float* batch_loss, void* stream);
+
 /* Attach a network to a batch: from then on every sensing pass (auv_reset,
  * auv_step*, auv_sense) also evaluates `head` of the network on the fresh
  * scans and leaves the result in AUV_BUF_CNN_OUT, f32 [V,out_dim].  On the
