@@ -891,9 +891,9 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         const double t = __longlong_as_double((long long)best[f]);
         const size_t out = (size_t)e0 * R + f;
         const float close = (float)(1.0 - div_by_const(t, range, a_out.inv_range));
-        a_out.ranges[out] = t;
-        a_out.hit[out] = (int)ids[f];
-        a_out.perception[out] = close;
+        __builtin_nontemporal_store(t, &a_out.ranges[out]);
+        __builtin_nontemporal_store((int)ids[f], &a_out.hit[out]);
+        __builtin_nontemporal_store(close, &a_out.perception[out]);
         if (a_out.cnn_w) reinterpret_cast<float*>(ids)[f] = close;  // the id slot becomes the network's input
     }
     if (a_out.cnn_w) {
