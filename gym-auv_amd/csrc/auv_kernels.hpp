@@ -454,6 +454,31 @@ __global__ __launch_bounds__(256) void k_encounter(EncArgs a) {
 // ---------------------------------------------------------------------------
 // LiDAR
 // ---------------------------------------------------------------------------
+// Squared distance of a polygon's farthest vertex from its pose point, or -1
+// unless every vertex lies strictly to the left of every edge it does not
+// belong to (strictly convex, counter-clockwise).  v: body-frame vertices,
+// nv of them in use.  A convex polygon seen from farther out than that shows
+// the sensor only its facing edges: an edge with a x e > 0 (outward side away
+// from the vessel) is then no LiDAR surface.  Seen from outside, every ray
+// meets a facing edge first, so only rays through a silhouette vertex could
+// tell the difference.
+__host__ __device__ inline double polygon_reach2(const double* v, int nv) {
+    if (nv < 3) return -1.0;
+    double reach2 = 0.0;
+    for (int k = 0; k < nv; ++k) {
+        const int k1 = (k + 1 < nv) ? k + 1 : 0;
+        const double ex = v[2 * k1] - v[2 * k], ey = v[2 * k1 + 1] - v[2 * k + 1];
+        const double rr = v[2 * k] * v[2 * k] + v[2 * k + 1] * v[2 * k + 1];
+        reach2 = rr > reach2 ? rr : reach2;
+        for (int j = 0; j < nv; ++j) {
+            if (j == k || j == k1) continue;
+            const double wx = v[2 * j] - v[2 * k], wy = v[2 * j + 1] - v[2 * k + 1];
+            if (!(ex * wy - ey * wx > 0.0)) return -1.0;
+        }
+    }
+    return reach2;
+}
+
 struct LidarArgs {
     Dims d;
     int TE;  // envs per workgroup
@@ -462,6 +487,7 @@ struct LidarArgs {
     const double* poly_pose;
     const double* poly_verts;
     const int32_t* poly_nv;
+    const double* poly_reach2;  // [V,P] polygon_reach2
     const double* ray_dirs;  // [R,2]
     double* ranges;          // [V,R]
     int32_t* hit;            // [V,R]
@@ -534,6 +560,17 @@ __global__ __launch_bounds__(256) void k_lidar(LidarArgs a) {
             ex = Bx - Ax;
             ey = By - Ay;
             nt = ax * ey - ay * ex;
+            // an edge of a convex polygon that faces away from a vessel outside it is no LiDAR surface:
+            // its record becomes the all-zero one of an unused slot
+            const double reach2 = a.poly_reach2[ep];
+            const double mx = X - a.state[e], my = Y - a.state[(size_t)V + e];
+            if (reach2 >= 0.0 && (mx * mx + my * my) > reach2 && nt > 0.0) {
+                ax = 0.0;
+                ay = 0.0;
+                ex = 0.0;
+                ey = 0.0;
+                nt = 0.0;
+            }
         }
         double* sg = seg + (size_t)i * 5;
         sg[0] = ax;

@@ -61,6 +61,7 @@ struct SceneGenArgs {
     int32_t* poly_nv;
     double* poly_heading;
     double* poly_beam;
+    double* poly_reach2;
     double* poly_rot;           // [V,P,NV,2]
     double* path;  // [V,6]
     double* init;  // [6,V]
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256) void k_scenegen(SceneGenArgs a) {
         a.poly_nv[ep_i] = 5;
         a.poly_heading[ep_i] = h;
         a.poly_beam[ep_i] = hw - (-hw);
+        a.poly_reach2[ep_i] = polygon_reach2(v, 5);
         double* rt = a.poly_rot + ep_i * NV * 2;
         for (int k = 0; k < NV; ++k) {
             rt[2 * k] = sc.c * v[2 * k] - sc.s * v[2 * k + 1];

@@ -166,6 +166,7 @@ struct SenseArgs {
     const int32_t* poly_nv;
     const double* poly_heading;
     const double* poly_beam;  // [V,P]
+    const double* poly_reach2;  // [V,P] polygon_reach2: which polygons show only their facing edges, and from how far out
     const double* poly_rot;   // [V,P,NV,2] R(heading) * body-frame vertex
     const double* ray_dirs;
     double* ranges;
@@ -535,6 +536,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         const int e = e0 + el;
         const size_t ep = (size_t)e * P + q;
         const int nv = a.poly_nv[ep];
+        const double reach2 = a.poly_reach2[ep];
         const double* p = a.poly_pose + ep * 6;
         // every vertex slot exists in memory, so the loads need not wait for nv
         const double* vb = a.poly_rot + ep * NV * 2;  // already turned to the ship's heading
@@ -598,8 +600,11 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
             const float fbx = fax + fex, fby = fay + fey;
             const float dmin = fast_sqrtf((float)dd);
             const float aa = fax * fax + fay * fay, bb = fbx * fbx + fby * fby;
-            if (dmin > frange) {
-                // wholly beyond sensor range: stays empty
+            // an edge of a convex polygon that faces away from a vessel outside it is no LiDAR surface (polygon_reach2)
+            const double cmx = X - px, cmy = Y - py;
+            const bool faces_away = reach2 >= 0.0 && (cmx * cmx + cmy * cmy) > reach2 && nt > 0.0;
+            if (dmin > frange || faces_away) {
+                // wholly beyond sensor range, or never a LiDAR surface: stays empty
             } else if (aa < 1e-6f || bb < 1e-6f || dmin < 1e-3f) {
                 iv.y = R;  // an endpoint (or the edge) is on top of the vessel: bearings are meaningless
             } else {

@@ -90,6 +90,8 @@ struct auv_sim {
     double* poly_heading = nullptr;
     double* poly_rot = nullptr;   // [V,P,NV,2] vertices turned to the ship's heading (world-frame offsets from its centre; a scene constant)
     double* poly_beam = nullptr;  // [V,P] extent of the body-frame vertices across the heading (a scene constant)
+    double* poly_reach2 = nullptr;  // [V,P] squared distance of the farthest vertex from the pose point, -1 unless the
+                                    // polygon is strictly convex and counter-clockwise (polygon_reach2; a scene constant)
     double* path = nullptr;
     double* ray_dirs = nullptr;
     double* init_stage = nullptr;  // [6,V] staging for reset
@@ -260,6 +262,7 @@ int launch_scenegen(auv_sim* h, hipStream_t st, const uint8_t* only_done) {
     ga.poly_nv = h->poly_nv;
     ga.poly_heading = h->poly_heading;
     ga.poly_beam = h->poly_beam;
+    ga.poly_reach2 = h->poly_reach2;
     ga.poly_rot = h->poly_rot;
     ga.path = h->path;
     ga.init = h->init_stage;
@@ -366,6 +369,7 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.poly_nv = h->poly_nv;
     sa.poly_heading = h->poly_heading;
     sa.poly_beam = h->poly_beam;
+    sa.poly_reach2 = h->poly_reach2;
     sa.poly_rot = h->poly_rot;
     sa.ray_dirs = h->ray_dirs;
     sa.ranges = bp<double>(h, AUV_BUF_RANGES);
@@ -476,6 +480,7 @@ int launch_sense(auv_sim* h, hipStream_t st, hipEvent_t* ev, int is_step) {
     la.poly_pose = bp<double>(h, AUV_BUF_POLY_POSE);
     la.poly_verts = h->poly_verts;
     la.poly_nv = h->poly_nv;
+    la.poly_reach2 = h->poly_reach2;
     la.ray_dirs = h->ray_dirs;
     la.ranges = bp<double>(h, AUV_BUF_RANGES);
     la.hit = bp<int32_t>(h, AUV_BUF_HIT);
@@ -681,6 +686,7 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     chk(alloc_raw(h, &h->poly_nv, (size_t)V * P));
     chk(alloc_raw(h, &h->poly_heading, (size_t)V * P));
     chk(alloc_raw(h, &h->poly_beam, (size_t)V * P));
+    chk(alloc_raw(h, &h->poly_reach2, (size_t)V * P));
     chk(alloc_raw(h, &h->path, (size_t)V * 6));
     chk(alloc_raw(h, &h->ray_dirs, (size_t)R * 2));
     chk(alloc_raw(h, &h->init_stage, (size_t)V * 6));
@@ -716,7 +722,7 @@ void auv_destroy(auv_handle h) {
     for (auto& ev : h->events) (void)hipEventDestroy(ev);
     for (auto& b : h->buf)
         if (b.ptr) (void)hipFree(b.ptr);
-    void* raw[] = {h->poly_verts, h->poly_rot, h->poly_nv, h->poly_heading, h->poly_beam, h->path, h->ray_dirs, h->init_stage, h->mask_stage,
+    void* raw[] = {h->poly_verts, h->poly_rot, h->poly_nv, h->poly_heading, h->poly_beam, h->poly_reach2, h->path, h->ray_dirs, h->init_stage, h->mask_stage,
                    h->circles0, h->poly_pose0, h->envrec, h->cnn_w, h->stats_ws};
     for (void* p : raw)
         if (p) (void)hipFree(p);
@@ -792,6 +798,10 @@ int auv_set_scene(auv_handle h, int32_t env_begin, int32_t env_count, const doub
             if (poly_nv[i] > 0) beam[i] = hi - lo;
         }
         HIP_TRY(h, hipMemcpy(h->poly_beam + b * d.P, beam.data(), n * d.P * sizeof(double), hipMemcpyHostToDevice));
+        // which polygons show the sensor only their facing edges, and from how far out
+        std::vector<double> reach2(n * d.P, -1.0);
+        for (size_t i = 0; i < n * d.P; ++i) reach2[i] = polygon_reach2(poly_verts + i * d.NV * 2, poly_nv[i]);
+        HIP_TRY(h, hipMemcpy(h->poly_reach2 + b * d.P, reach2.data(), n * d.P * sizeof(double), hipMemcpyHostToDevice));
         // every vertex slot turned to its ship's heading: R(h) * body, the offsets the sensing kernel adds to the centre
         std::vector<double> rot(n * d.P * d.NV * 2);
         for (size_t i = 0; i < n * d.P; ++i) {

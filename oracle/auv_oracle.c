@@ -238,6 +238,26 @@ static void world_vertex(const double *pose, const double *v, double *wx, double
 }
 
 /* everything that follows the state update, for env e (oracle/auv_oracle.py: OracleEnv.sense) */
+/* oracle/auv_oracle.py: polygon_reach2 -- squared distance of the farthest vertex from the pose point, or -1
+ * unless every vertex lies strictly to the left of every edge it does not belong to (strictly convex,
+ * counter-clockwise).  v: body-frame vertices [NV,2], nv of them in use. */
+static double oc_polygon_reach2(const double *v, int nv) {
+    if (nv < 3) return -1.0;
+    double reach2 = 0.0;
+    for (int k = 0; k < nv; ++k) {
+        const int k1 = (k + 1 < nv) ? k + 1 : 0;
+        const double ex = v[2 * k1] - v[2 * k], ey = v[2 * k1 + 1] - v[2 * k + 1];
+        const double rr = v[2 * k] * v[2 * k] + v[2 * k + 1] * v[2 * k + 1];
+        if (rr > reach2) reach2 = rr;
+        for (int j = 0; j < nv; ++j) {
+            if (j == k || j == k1) continue;
+            const double wx = v[2 * j] - v[2 * k], wy = v[2 * j + 1] - v[2 * k + 1];
+            if (!(ex * wy - ey * wx > 0.0)) return -1.0;
+        }
+    }
+    return reach2;
+}
+
 static void oc_sense_env(const oc_config *cf, const oc_buffers *b, int e, int is_step) {
     const int V = cf->V, R = cf->R, C = cf->C, P = cf->P, NV = cf->NV, O = C + P;
     const double px = b->state[e], py = b->state[(size_t)V + e], psi = b->state[2 * (size_t)V + e];
@@ -265,6 +285,10 @@ static void oc_sense_env(const oc_config *cf, const oc_buffers *b, int e, int is
     }
     for (int p = 0; p < P; ++p) {
         const int nv = nvs[p];
+        /* a convex polygon seen from beyond its farthest vertex shows only the edges that face the vessel */
+        const double reach2 = oc_polygon_reach2(verts + (size_t)p * NV * 2, nv);
+        const double pmx = pose[p * 6] - px, pmy = pose[p * 6 + 1] - py;
+        const int outside = reach2 >= 0.0 && (pmx * pmx + pmy * pmy) > reach2;
         for (int k = 0; k < nv; ++k) {   /* edges k >= nv never count */
             const int k1 = (k + 1 < nv) ? k + 1 : 0;
             double Ax, Ay, Bx, By;
@@ -276,6 +300,7 @@ static void oc_sense_env(const oc_config *cf, const oc_buffers *b, int e, int is
             sey[n_seg] = By - Ay;
             snt[n_seg] = sax[n_seg] * sey[n_seg] - say[n_seg] * sex[n_seg];
             sid[n_seg] = C + p;
+            if (outside && snt[n_seg] > 0.0) continue;   /* faces away: not a LiDAR surface */
             ++n_seg;
         }
     }

@@ -227,7 +227,36 @@ def polygon_world_vertices(poly_pose, poly_verts):
 # ----------------------------------------------------------------------------
 # a3: LiDAR
 # ----------------------------------------------------------------------------
-def lidar(state, circles, poly_pose, poly_verts, poly_nv, ray_dirs, sensor_range):
+def polygon_reach2(poly_verts, poly_nv):
+    """Per polygon [V,P]: the squared distance of its farthest vertex from its
+    pose point (body frame), or -1 when the polygon is not strictly convex and
+    counter-clockwise (every vertex strictly to the left of every edge it does
+    not belong to).  A convex polygon seen from outside the circle of that
+    radius about its pose point shows the sensor only the edges that face it
+    (`lidar`)."""
+    v = np.asarray(poly_verts, dtype=np.float64)
+    nv = np.asarray(poly_nv)
+    NV = v.shape[2]
+    convex = nv >= 3
+    reach2 = np.zeros(nv.shape)
+    for k in range(NV):
+        in_k = k < nv
+        k1 = np.where(k + 1 < nv, k + 1, 0)
+        vkx, vky = v[:, :, k, 0], v[:, :, k, 1]
+        v1x = np.take_along_axis(v[..., 0], k1[..., None], axis=2)[..., 0]
+        v1y = np.take_along_axis(v[..., 1], k1[..., None], axis=2)[..., 0]
+        ex, ey = v1x - vkx, v1y - vky
+        rr = vkx * vkx + vky * vky
+        reach2 = np.where(in_k & (rr > reach2), rr, reach2)
+        for j in range(NV):
+            other = in_k & (j < nv) & (j != k) & (j != k1)
+            wx, wy = v[:, :, j, 0] - vkx, v[:, :, j, 1] - vky
+            left = (ex * wy - ey * wx) > 0.0
+            convex = convex & (left | ~other)
+    return np.where(convex, reach2, -1.0)
+
+
+def lidar(state, circles, poly_pose, poly_verts, poly_nv, ray_dirs, sensor_range, poly_reach2=None):
     """Nearest boundary hit per ray.
 
     Returns (ranges [V,R] f64, hit [V,R] i32).  Obstacle ids: circles
@@ -236,6 +265,13 @@ def lidar(state, circles, poly_pose, poly_verts, poly_nv, ray_dirs, sensor_range
     id order (polygon edges in vertex order) and a hit at parameter t replaces
     the best only when 0 <= t < best, so ties keep the lowest id and a hit at
     exactly sensor_range does not count.
+
+    A return comes from a surface that faces the sensor: an edge of a convex
+    polygon (`polygon_reach2` >= 0) whose outward side faces away from the
+    vessel (a x e > 0) is not tested while the vessel is farther from the
+    polygon's pose point than its farthest vertex (and so outside it).  Seen
+    from there every ray meets a facing edge first, so the scan is the same
+    except when a ray passes exactly through a silhouette vertex.
     """
     V = state.shape[1]
     R = ray_dirs.shape[0]
@@ -273,8 +309,13 @@ def lidar(state, circles, poly_pose, poly_verts, poly_nv, ray_dirs, sensor_range
         if P:
             wx, wy = polygon_world_vertices(poly_pose, poly_verts)
             NV = poly_verts.shape[2]
+            if poly_reach2 is None:
+                poly_reach2 = polygon_reach2(poly_verts, poly_nv)
             for p in range(P):
                 nv = poly_nv[:, p]
+                mx = poly_pose[:, p, 0] - state[0]
+                my = poly_pose[:, p, 1] - state[1]
+                outside = (poly_reach2[:, p] >= 0.0) & ((mx * mx + my * my) > poly_reach2[:, p])
                 for k in range(NV):
                     k1 = np.where(k + 1 < nv, k + 1, 0)
                     Ax = wx[:, p, k]
@@ -290,7 +331,8 @@ def lidar(state, circles, poly_pose, poly_verts, poly_nv, ray_dirs, sensor_range
                     ns = ax * dy - ay * dx
                     inseg = np.where(den > 0.0, (ns >= 0.0) & (ns <= den),
                                      (ns <= 0.0) & (ns >= den))
-                    ok = (k < nv)[:, None] & (den != 0.0) & inseg
+                    faces = ~(outside[:, None] & (nt > 0.0))
+                    ok = (k < nv)[:, None] & (den != 0.0) & inseg & faces
                     t = nt / np.where(ok, den, 1.0)
                     consider(t, ok, C + p)
     return best, hit
@@ -513,6 +555,7 @@ class OracleEnv:
         if poly_heading is None:
             poly_heading = np.zeros(self.poly_pose.shape[:2])
         self.poly_heading = np.array(poly_heading, dtype=np.float64, copy=True)
+        self.poly_reach2 = polygon_reach2(self.poly_verts, self.poly_nv)
         self.circles0 = self.circles.copy()
         self.poly_pose0 = self.poly_pose.copy()
 
@@ -556,8 +599,9 @@ class OracleEnv:
     def sense(self, is_step=False):
         cfg = self.cfg
         R = cfg["sensor_range"]
+        self.poly_reach2 = polygon_reach2(self.poly_verts, self.poly_nv)   # the vertices may have been regenerated
         self.ranges, self.hit = lidar(self.state, self.circles, self.poly_pose,
-                                      self.poly_verts, self.poly_nv, self.ray_dirs, R)
+                                      self.poly_verts, self.poly_nv, self.ray_dirs, R, self.poly_reach2)
         (self.obst_dist, self.collision, self.min_dist,
          self.min_idx) = obstacle_distances(self.state, self.circles, self.poly_pose,
                                             self.poly_verts, self.poly_nv,
@@ -625,10 +669,11 @@ class OracleEnv:
 # scalar (one vessel, pure Python float) forms used to cross-check the
 # vectorised code on small cases
 # ----------------------------------------------------------------------------
-def lidar_scalar(p, psi, circles, polys_world, ray_dirs, sensor_range):
+def lidar_scalar(p, psi, circles, polys_world, ray_dirs, sensor_range, poly_info=None):
     """p = (x, y); circles = [(cx, cy, rad)]; polys_world = list of vertex
-    lists [(x, y), ...] (empty list = absent).  Python-float restatement of
-    `lidar` for one vessel."""
+    lists [(x, y), ...] (empty list = absent); poly_info = per polygon
+    (pose x, pose y, reach2 of `polygon_reach2`), None: no polygon is taken as
+    convex.  Python-float restatement of `lidar` for one vessel."""
     import math
     s, c = sincos(np.float64(psi))
     s = float(s)
@@ -661,6 +706,12 @@ def lidar_scalar(p, psi, circles, polys_world, ray_dirs, sensor_range):
                 hit = j
         for q, verts in enumerate(polys_world):
             nv = len(verts)
+            outside = False
+            if poly_info is not None:
+                X, Y, reach2 = (float(t) for t in poly_info[q])
+                mx = X - p[0]
+                my = Y - p[1]
+                outside = reach2 >= 0.0 and (mx * mx + my * my) > reach2
             for k in range(nv):
                 Ax, Ay = verts[k]
                 Bx, By = verts[(k + 1) % nv]
@@ -677,7 +728,7 @@ def lidar_scalar(p, psi, circles, polys_world, ray_dirs, sensor_range):
                     ok = den <= ns <= 0.0
                 else:
                     ok = False
-                if not ok:
+                if not ok or (outside and nt > 0.0):
                     continue
                 t = nt / den
                 if t >= 0.0 and t < best:

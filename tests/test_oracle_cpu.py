@@ -125,8 +125,9 @@ def test_vectorised_lidar_equals_scalar_form():
         polys = [[(wx[e, p, k], wy[e, p, k]) for k in range(env.poly_nv[e, p])]
                  for p in range(cfg["n_polys"])]
         circ = [tuple(env.circles[e, j, :3]) for j in range(cfg["n_circles"])]
+        info = [(env.poly_pose[e, p, 0], env.poly_pose[e, p, 1], env.poly_reach2[e, p]) for p in range(cfg["n_polys"])]
         r, i = O.lidar_scalar((env.state[0, e], env.state[1, e]), env.state[2, e], circ, polys,
-                              env.ray_dirs, cfg["sensor_range"])
+                              env.ray_dirs, cfg["sensor_range"], info)
         assert np.array_equal(r, env.ranges[e]) and np.array_equal(i, env.hit[e])
 
 

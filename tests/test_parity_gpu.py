@@ -590,3 +590,66 @@ def test_vec_env_gym_contract():
         obs, rew, done, info = venv.step(a)
     assert (venv.sim.read("episode") == 1).all() and not np.array_equal(venv.sim.read("circles"), first)
     venv.close()
+
+
+def test_facing_edge_rule_on_every_kind_of_polygon():
+    """Convex counter-clockwise polygons show the sensor only their facing edges once the vessel is beyond their
+    farthest vertex; clockwise, concave, degenerate and too-short vertex lists never do.  Vessels on a grid that
+    covers inside, on the reach circle and far outside; both device paths against the numpy and the C oracle."""
+    from oracle import c_oracle
+
+    side = 21
+    V = side * side
+    P, NV = 6, 6
+    cfg = params.make_config(V, 0, P, NV)
+    hexagon = scenarios.ngon(np.full(6, 12.0))
+    shapes = [
+        (hexagon, 6),                                                         # convex, counter-clockwise
+        (hexagon[::-1].copy(), 6),                                            # the same, clockwise
+        (np.array([[-10, -6], [10, 0], [-10, 6], [-4, 0], [0, 0], [0, 0.0]]), 4),   # concave arrow
+        (np.array([[-8, 0], [0, 0], [8, 0], [0, 0], [0, 0], [0, 0.0]]), 3),         # three collinear points
+        (scenarios.ship_polygon(9.0).reshape(5, 2).tolist() + [[0.0, 0.0]], 5),     # a ship
+        (np.array([[-5, -5], [5, -5], [5, 5], [-5, 5], [0, 0], [0, 0.0]]), 4),      # a square
+    ]
+    verts = np.zeros((V, P, NV, 2))
+    nv = np.zeros((V, P), dtype=np.int32)
+    pose = np.zeros((V, P, 6))
+    heading = np.zeros((V, P))
+    centres = [(-40.0, -25.0), (0.0, -25.0), (40.0, -25.0), (-40.0, 25.0), (0.0, 25.0), (40.0, 25.0)]
+    for q, ((sh, n), (cx, cy)) in enumerate(zip(shapes, centres)):
+        verts[:, q] = np.asarray(sh, dtype=np.float64)
+        nv[:, q] = n
+        h = 0.3 * q
+        pose[:, q] = (cx, cy, np.cos(h), np.sin(h), 0.2, -0.1)
+        heading[:, q] = h
+    gx, gy = np.meshgrid(np.linspace(-60, 60, side), np.linspace(-45, 45, side))
+    init = np.zeros((6, V))
+    init[0], init[1], init[2] = gx.ravel(), gy.ravel(), np.linspace(-3, 3, V)
+    scene = {"circles": np.zeros((V, 0, 5)), "poly_pose": pose, "poly_verts": verts, "poly_nv": nv,
+             "poly_heading": heading, "init_state": init, "path": scenarios._straight_path(V, init[2])}
+    r2 = O.polygon_reach2(verts, nv)[0]
+    assert (r2 >= 0).tolist() == [True, False, False, False, True, True]
+    env = make_oracle(cfg, scene)
+    cenv = c_oracle.COracleEnv(cfg, params.ray_table(cfg["n_rays"]), threads=2)
+    cenv.set_scene(scene["circles"], pose, verts, nv, heading)
+    cenv.set_path(scene["path"])
+    env.reset(init)
+    cenv.reset(init)
+    assert same_bits(cenv.ranges, env.ranges) and same_bits(cenv.hit, env.hit)
+    acts = scenarios.random_actions(V, 3, seed=12)
+    for mode in (0, 1):
+        sim = make_sim(cfg, scene, lidar_mode=mode)
+        sim.reset(init)
+        env.reset(init)
+        assert_all_equal(sim, env, f"facing-edge rule, mode {mode}, reset")
+        for k in range(3):
+            sim.step_host(acts[k])
+            env.step(acts[k])
+            assert_all_equal(sim, env, f"facing-edge rule, mode {mode}, step {k}")
+        sim.close()
+    cenv.close()
+    # the rule changes nothing here that a full test of every edge would see
+    full = O.lidar(env.state, env.circles, env.poly_pose, env.poly_verts, env.poly_nv, env.ray_dirs,
+                   cfg["sensor_range"], np.full((V, P), -1.0))
+    assert same_bits(full[0], env.ranges) and same_bits(full[1], env.hit)
+    assert env.collision.any() and not env.collision.all()
