@@ -122,9 +122,7 @@ __device__ __forceinline__ RefMotion reference_motion(double ovx, double ovy, do
 // p . v = dist (m . w)/(|m||w|).  S half; -inf for an absent slot (!present),
 // which makes the clipped sum 0.  Every present obstacle has a risk, whatever
 // its distance.
-__device__ __forceinline__ double risk_reference_s(double mx, double my, double ovx, double ovy, double vox, double voy,
-                                                   double dist, double cpsi, double spsi, double psi, bool present) {
-    const RefMotion rm = reference_motion(ovx, ovy, vox, voy, cpsi, spsi, psi);
+__device__ __forceinline__ double risk_reference_s_of(const RefMotion& rm, double mx, double my, double dist, bool present) {
     const double mm = mx * mx + my * my;
     const double den = __builtin_sqrt(mm * rm.ww);
     const double dens = den > 0.0 ? den : 1.0;
@@ -133,6 +131,11 @@ __device__ __forceinline__ double risk_reference_s(double mx, double my, double 
     const double cross = dist * ((mx * rm.wy - my * rm.wx) / dens);
     const double s_half = cri_cpa_range_half(along, cross, moving, dist);
     return present ? s_half : 0.0 - __builtin_inf();
+}
+
+__device__ __forceinline__ double risk_reference_s(double mx, double my, double ovx, double ovy, double vox, double voy,
+                                                   double dist, double cpsi, double spsi, double psi, bool present) {
+    return risk_reference_s_of(reference_motion(ovx, ovy, vox, voy, cpsi, spsi, psi), mx, my, dist, present);
 }
 
 // T half from the body bearing b = wrap(atan2(m) - psi); the aspect is

@@ -658,11 +658,12 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     const int total = n_cp + n_ep;
     const bool fits = total <= cap;
 
-    // ---- phase 2: obstacle-level outputs.  Four independent tasks per
-    // obstacle, each on a wave of its own so that no wave runs two of the long
-    // fp64 chains back to back: 0 = distance (polygons: from their edges; also
-    // the deferred write-back of the advanced position), relative speed and
-    // the per-env summary; 1 = bearing; 2 = course; 3 = risk.
+    // ---- phase 2: obstacle-level outputs.  Two tasks per obstacle, each on a
+    // wave of its own: 0 = distance (polygons: from their edges; also the
+    // deferred write-back of the advanced position) and the per-env summary;
+    // 1 = bearing, course, relative speed and risk, which share the bearing
+    // and the relative motion.  The kernel is bound by instruction issue, not by
+    // the length of one wave's chain: the other waves go straight to the sweeps.
     {
         const SenseArgs a2 = reload_args();
         const SenseArgs& a = a2;
@@ -698,7 +699,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         // when an env's obstacles sit in an aligned power-of-two group of lanes
         // of one wave, its nearest obstacle is a shuffle reduction
         const bool lanes_per_env = O > 0 && (O & (O - 1)) == 0 && TE * O <= 64;
-        const int n_tasks = a.with_meta ? 4 : 1;
+        const int n_tasks = a.with_meta ? 2 : 1;
         for (int task = wave; task < n_tasks; task += n_waves) {
             for (int i0 = 0; i0 < n_obst || (task == 0 && i0 == 0); i0 += 64) {
                 const int i = i0 + lane;
@@ -712,15 +713,9 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                     const double mx = ob[OB_MX * ob_n], my = ob[OB_MY * ob_n], rvx = ob[OB_RVX * ob_n], rvy = ob[OB_RVY * ob_n];
                     const size_t eo = (size_t)e * O + o;
                     double* m = a.meta + eo * 5;
-                    // RISK == 1: the heading, speed and course columns follow the reference's
-                    // conventions and are written with the bearing / course tasks
+                    // RISK == 1: the heading, speed and course columns follow the reference's conventions
                     const double* ov = o < C ? a.circles + ((size_t)e * C + o) * 5 + 3
                                              : a.poly_pose + ((size_t)e * P + (o - C)) * 6 + 4;
-                    auto ref_motion = [&]() -> RefMotion {
-                        const double* er = a.envrec + (size_t)e * ER_COUNT;
-                        return reference_motion(ov[0], ov[1], er[ER_VOX], er[ER_VOY], er[ER_COS], er[ER_SIN],
-                                                a.state[2 * (size_t)V + e]);
-                    };
                     if (task == 0) {
                         dist = hull_distance(ob, el, o);
                         double hd = 0.0;
@@ -740,27 +735,27 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                             m[0] = hd;
                             m[2] = __builtin_sqrt(rvx * rvx + rvy * rvy);
                         }
-                    } else if (task == 3) {
+                    } else {
+                        // task 1: bearing, course, relative speed and risk of the obstacle, on one wave: the
+                        // bearing and the reference's relative motion are formed once and shared
+                        const double psi = a.state[2 * (size_t)V + e];
+                        const double bearing = wrap_angle(atan2_det(my, mx) - psi);
+                        m[3] = bearing;
                         if (RISK == 1) {
                             const double* er = a.envrec + (size_t)e * ER_COUNT;
+                            const RefMotion rm = reference_motion(ov[0], ov[1], er[ER_VOX], er[ER_VOY], er[ER_COS], er[ER_SIN], psi);
+                            m[2] = rm.still ? rm.ss : __builtin_sqrt(rm.rr);
+                            m[4] = rm.still ? (psi > 0.0 ? 0.0 : 0.0 - kPi) : atan2_det(rm.wy, rm.wx);
+                            if (a.refresh_heading || er[ER_RESET] != 0.0)
+                                m[0] = (ov[0] == 0.0 && ov[1] == 0.0) ? 0.0 : atan2_det(ov[1], ov[0]);
                             const double dref = ref_distance(ob, el, o, mx, my);
-                            a.risk[eo] = risk_reference(mx, my, ov[0], ov[1], er[ER_VOX], er[ER_VOY], dref, er[ER_COS],
-                                                        er[ER_SIN], a.state[2 * (size_t)V + e], dref < __builtin_inf());
+                            a.risk[eo] = cri_sum(risk_reference_s_of(rm, mx, my, dref, dref < __builtin_inf()),
+                                                 risk_reference_t(mx, my, ov[0], ov[1], bearing));
                         } else {
+                            m[4] = wrap_angle(atan2_det(rvy, rvx) - psi);
                             a.risk[eo] = risk_index(mx, my, rvx, rvy, rvx * rvx + rvy * rvy, hull_distance(ob, el, o), range,
                                                     a.inv_range, a.w_d, a.w_c, a.t_c);
                         }
-                    } else if (RISK == 1 && task == 2) {
-                        const RefMotion rm = ref_motion();
-                        const double psi = a.state[2 * (size_t)V + e];
-                        m[2] = rm.still ? rm.ss : __builtin_sqrt(rm.rr);
-                        m[4] = rm.still ? (psi > 0.0 ? 0.0 : 0.0 - kPi) : atan2_det(rm.wy, rm.wx);
-                    } else {
-                        const double psi = a.state[2 * (size_t)V + e];
-                        const double ang = wrap_angle(atan2_det(task == 1 ? my : rvy, task == 1 ? mx : rvx) - psi);
-                        m[2 + task] = ang;
-                        if (RISK == 1 && task == 1 && (a.refresh_heading || a.envrec[(size_t)e * ER_COUNT + ER_RESET] != 0.0))
-                            m[0] = (ov[0] == 0.0 && ov[1] == 0.0) ? 0.0 : atan2_det(ov[1], ov[0]);
                     }
                 }
                 if (task == 0 && lanes_per_env) {
@@ -809,7 +804,9 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
 #pragma unroll
         for (int j = 0; j < kKeep; ++j) {
             kept[j].ok = false;
-            const int w = tid + j * nthr;
+            // later rounds start half a workgroup on: the short end of the list falls to the wave that
+            // ran the long task of phase 2
+            const int w = (j == 0 ? tid : ((tid + (nthr >> 1)) & (nthr - 1))) + j * nthr;
             if (w < total) {
                 AUV_CHECK((w < n_cp ? w : cap - n_ep + (w - n_cp)) >= 0 && (w < n_cp ? w : cap - n_ep + (w - n_cp)) < cap);
                 kept[j] = pair_test<FIXED>(pair_get(w < n_cp ? w : cap - n_ep + (w - n_cp)), R, n_circ, range, meta, env, circ,
