@@ -213,6 +213,10 @@ def main():
     ap.add_argument("--risk-model", default="reference", choices=["reference", "cpa"],
                     help="risk index: the reference's own (recovered from its dataset files; default), or the "
                          "self-defined closest-point-of-approach index")
+    ap.add_argument("--dataset-rows", default="auto", choices=["auto", "on", "off"],
+                    help="after the timed rollouts, regenerate dataset rows (LiDAR / risk / metadata text files) "
+                         "from the running batch for 25 steps and report rows/s; auto: for the dense cfg5 workload, "
+                         "whose purpose that is")
     ap.add_argument("--gather-scans", action="store_true",
                     help="also gather the final scans of every rank on rank 0 once per rollout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -383,6 +387,33 @@ def main():
         e1.synchronize()
         cnn_ms = e0.elapsed_time(e1) / args.steps
 
+    # what cfg5 is for: regenerating the dataset files from the running batch (outside every timed region above)
+    dataset_rate = None
+    if rank == 0 and (args.dataset_rows == "on" or (args.dataset_rows == "auto" and args.workload.startswith("cfg5"))):
+        import shutil
+        import tempfile
+
+        from gym_auv_amd import dataset as D
+
+        tmp = tempfile.mkdtemp(prefix="auv_rows_")
+        try:
+            sim.reset(scene["init_state"], stream=stream)
+            w = D.DatasetWriter(tmp)
+            lg = D.DatasetLogger(sim, w)
+            t0 = time.perf_counter()
+            for k in range(25):
+                sim.step_device(ptrs[k % n_act], stream=stream)
+                lg.after_step(stream)
+            dt_rows = time.perf_counter() - t0
+            w.close()
+            size = sum(os.path.getsize(pth) for pth in w.paths.values())
+            dataset_rate = {"rows_per_s": w.rows / dt_rows, "rows": w.rows, "seconds": dt_rows,
+                            "text_MB": size / 1e6,
+                            "what": "25 steps, every env logged every 5th step of its episode through DatasetLogger "
+                                    f"(page-locked reads, native %.18e formatter): {R} ranges + risk + metadata per row"}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
     t = torch.tensor(times, device=dev, dtype=torch.float64)
     auv_dist.all_reduce(t, op=dist.ReduceOp.MAX)   # every repeat: the slowest rank
     times = sorted(t.tolist())
@@ -421,6 +452,8 @@ def main():
                           {"k_dynamics": vessel_s * 1e3, "k_encounter": enc_s * 1e3, "k_lidar": sense_s * 1e3}),
             "episode_stats": stats,
         }
+        if dataset_rate is not None:
+            out["dataset_regeneration"] = dataset_rate
         if cnn_ms is not None:
             out["kernel_ms"]["k_cnn"] = cnn_ms
             cb = float(V) * (720 + 4 * net.out_dim("features"))
