@@ -81,7 +81,12 @@ def cpu_baseline(name, n_envs, steps, threads, scalar_envs=4):
         env.step(acts[k])
     dt = time.perf_counter() - t0
     env.close()
-    n_np, s_np = min(n_envs, 2048), min(steps, 10)
+    # the numpy legs are sized by the scene: about as many ray-primitive pairs as 2,048 envs of the default scene
+    per_env = w_prims = None
+    from gym_auv_amd.scenarios import WORKLOADS
+    wl = WORKLOADS[name]
+    per_env = wl["R"] * (wl["C"] + wl["P"] * wl["NV"])
+    n_np, s_np = max(16, min(n_envs, 2048, int(2048 * 8640 / per_env))), min(steps, 10)
     cfg2, scene2 = scenarios.make_workload(name, n_envs=n_np)
     env2 = make_oracle(cfg2, scene2)
     env2.reset(scene2["init_state"])

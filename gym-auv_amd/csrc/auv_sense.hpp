@@ -202,7 +202,7 @@ struct SenseLayout {
 //   best[TE*R] u64     obst: 5 fields [TE*O] mx,my,rvx,rvy,dist then 3 fields [TE*P] x,y,heading
 //                      (field-major: the lanes of a wave walk the banks)
 //   edist[TE*S] f64    meta[NP] int2 {first | cnt<<16, env | obstacle<<8}
-//   ids[TE*R]   pairs[cap]   ecross[TE*S]   wsum[16]
+//   ids[TE*R]   pairs[cap]   ecross[TE*S]   wsum[24]
 //   offs[NP+1] (only the overflow path, after phase 2 is over) lies over obst.
 // With a network evaluated in-kernel (cnn_kind >= 0) its weights and two
 // activation buffers per env reuse the bytes in front of best[], which are
@@ -237,7 +237,7 @@ __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P,
     L.pairs = o; o += (size_t)cap * (packed ? 2 : 4);
     L.ecross = o; o += (size_t)TE * S * (packed ? 1 : 4);
     o = (o + 3) & ~(size_t)3;
-    L.wsum = o; o += 16 * 4;
+    L.wsum = o; o += 24 * 4;
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
@@ -354,6 +354,7 @@ __device__ unsigned long long g_violations = 0ull;
 #define AUV_CHECK(cond)
 #endif
 
+constexpr int kCntCircle = 16, kCntEdge = 17;  // slots of wsum[] that count the circle and the edge pairs
 constexpr int kKeep = 4;  // pair-list passes whose hit keys stay in registers between the two sweeps
 
 // The scene shape of the reference's default scenario at the benchmark's size:
@@ -431,7 +432,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     auto ecross_get = [&](int idx) -> int {
         return FIXED ? (int)reinterpret_cast<const unsigned char*>(ecross)[idx] : ecross[idx];
     };
-    int* wsum = reinterpret_cast<int*>(lds_raw + L.wsum);  // [0..7] wave sums of the fallback scan, [14],[15] pair counters
+    int* wsum = reinterpret_cast<int*>(lds_raw + L.wsum);  // [0..15] wave sums of the fallback scan, then the two pair counters
     const int e0 = blockIdx.x * TE;
     const int ne = min(TE, V - e0);
     const int n_circ = ne * C;
@@ -450,11 +451,11 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
 
     AUV_STAMP(0);
     // ---- phase 0: accumulators.  The pair list is filled from both ends:
-    // circle pairs grow up from slot 0 (count in wsum[14]), edge pairs grow down
-    // from slot cap (count in wsum[15]), so a wave of the sweep sees one kind.
+    // circle pairs grow up from slot 0 (count in wsum[kCntCircle]), edge pairs grow down
+    // from slot cap (count in wsum[kCntEdge]), so a wave of the sweep sees one kind.
     if (tid == 0) {
-        wsum[14] = 0;
-        wsum[15] = 0;
+        wsum[kCntCircle] = 0;
+        wsum[kCntEdge] = 0;
     }
     // heading sin/cos of the tile's vessels: requested now, filed at the end of
     // phase 1, so that the first barrier does not wait for global memory
@@ -522,7 +523,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         AUV_CHECK(i >= 0 && i < TE * C && el >= 0 && el < ne && j >= 0 && j < C && iv.x >= 0 && iv.x < R && iv.y <= R);
         meta[i] = pack_meta(iv.x, iv.y, el, j);
         if (iv.y > 0) {
-            const int base = atomicAdd(&wsum[14], iv.y);
+            const int base = atomicAdd(&wsum[kCntCircle], iv.y);
             const int room = min(iv.y, cap - base);  // writes stay inside the list even when it overflows
             AUV_CHECK(base >= 0 && (room <= 0 || base + room <= cap));
             for (int k = 0; k < room; ++k) pair_put(base + k, (unsigned int)i, (unsigned int)k);
@@ -632,7 +633,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         AUV_CHECK(i >= 0 && i < TE * S && el >= 0 && el < ne && q >= 0 && q < P && iv.x >= 0 && iv.x < R && iv.y <= R);
         meta[n_circ + i] = pack_meta(iv.x, iv.y, el, C + q);
         if (iv.y > 0) {
-            const int used = atomicAdd(&wsum[15], iv.y);
+            const int used = atomicAdd(&wsum[kCntEdge], iv.y);
             const int top = cap - used;  // exclusive upper slot of this primitive's run
             const int room = min(iv.y, top);
             AUV_CHECK(top <= cap && (room <= 0 || top - room >= 0));
@@ -648,7 +649,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     AUV_STAMP(2);
     __syncthreads();
     AUV_STAMP(3);
-    const int n_cp = wsum[14], n_ep = wsum[15];
+    const int n_cp = wsum[kCntCircle], n_ep = wsum[kCntEdge];
 #ifdef AUV_PHASE_STAMPS
     if (g_stamps && tid == 0) {
         g_stamps[(size_t)blockIdx.x * 64 + 14] = n_cp;
@@ -915,7 +916,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
 
 // generic shape
 template <int RISK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) void k_sense(SenseArgs a) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_sense(SenseArgs a) {
     sense_tile<RISK, false>(a);
 }
 

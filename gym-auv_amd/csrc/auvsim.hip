@@ -215,8 +215,9 @@ void set_raster_tile(auv_sim* h, int want) {
     h->raster_te = te;
     h->raster_cap = cap;
     h->raster_lds = sense_layout(te, d.R, d.C, d.P, d.NV, cap, cf).total;
-    // a tile with many primitives (dense scenes) keeps 8 waves busy; the usual one is best with 4
-    h->sense_block = h->block_want ? h->block_want : ((long long)te * (d.C + S) >= 768 ? 512 : 256);
+    // a tile with many primitives (dense scenes) keeps 8 or 16 waves busy; the usual one is best with 4
+    const long long prims = (long long)te * (d.C + S);
+    h->sense_block = h->block_want ? h->block_want : (prims >= 1024 ? 1024 : prims >= 768 ? 512 : 256);
     // the pair list packs (primitive, ray offset) into 16 bits each
     if ((long long)te * (d.C + S) > 65535 || d.R > 65535) h->raster_lds = (size_t)1 << 30;
 }
@@ -1024,8 +1025,8 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
             h->lidar_mode = value;
             return AUV_OK;
         case AUV_OPT_SENSE_BLOCK:
-            if (value != 64 && value != 128 && value != 256 && value != 512)
-                return fail(h, AUV_ERR_ARG, "auv_set_option: k_sense workgroup size must be 64, 128, 256 or 512");
+            if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
+                return fail(h, AUV_ERR_ARG, "auv_set_option: k_sense workgroup size must be 64, 128, 256, 512 or 1024");
             h->block_want = value;
             h->sense_block = value;
             return AUV_OK;

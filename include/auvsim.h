@@ -113,8 +113,8 @@ typedef enum auv_buffer {
 typedef enum auv_option {
     AUV_OPT_LIDAR_MODE = 0,   /* AUV_LIDAR_RASTER (default) | AUV_LIDAR_ALL_PAIRS */
     AUV_OPT_RASTER_TILE = 1,  /* envs per workgroup of the rasterising kernel; 0 = auto */
-    AUV_OPT_SENSE_BLOCK = 2,  /* threads per k_sense workgroup: 64, 128, 256 or 512 (default: 256, 512 for
-                               * tiles of 768 primitives or more) */
+    AUV_OPT_SENSE_BLOCK = 2,  /* threads per k_sense workgroup: 64, 128, 256, 512 or 1024 (default: 256; 512 for
+                               * tiles of 768 primitives or more, 1024 from 1024 primitives) */
     AUV_OPT_AUTO_RESET = 3,   /* 1: an env whose done flag is set restarts INSIDE the next auv_step, with no
                                * host round trip: its action is ignored, the vessel takes the initial state
                                * of the most recent auv_reset call, its step counter is cleared, its

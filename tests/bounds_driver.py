@@ -41,6 +41,7 @@ def main():
     for V, R, Cn, P, NV, ns, tile, block in [(300, 180, 8, 8, 5, None, 0, 0), (130, 1000, 2, 3, 7, 7, 1, 512),
                                              (67, 180, 16, 5, 16, 16, 0, 64), (259, 90, 7, 1, 4, 4, 5, 128),
                                              (1000, 64, 1, 1, 3, 3, 64, 64), (40, 720, 128, 128, 8, 8, 0, 0),
+                                             (33, 720, 40, 40, 8, 8, 2, 1024),
                                              (1027, 180, 8, 8, 5, None, 4, 256)]:   # the compile-time shape, narrow LDS image
         cfg = params.make_config(V, Cn, P, NV, n_rays=R, max_steps=6)
         scene = scenarios.make_scene(V, Cn, P, NV, seed=V, extent=50.0, n_sides=ns, width=(6.0, 40.0))

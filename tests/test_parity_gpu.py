@@ -455,6 +455,7 @@ SHAPES = [
     (130, 180, 5, 6, 5, None, 16, 256),
     (259, 90, 7, 1, 4, 4, 5, 0),
     (31, 360, 0, 9, 8, 6, 2, 512),
+    (33, 720, 40, 40, 8, 8, 2, 1024),   # sixteen waves per workgroup (dense tiles take this size by default)
     (1000, 64, 1, 1, 3, 3, 64, 64),
     (1027, 180, 8, 8, 5, 5, 4, 256),   # the shape with a compile-time instantiation of the sensing kernel; last tile short
 ]
