@@ -47,7 +47,7 @@ def sense_bytes_per_env(R, C, P, NV, meta_fields=5):
     reference's index the heading column is a constant of the scene and is
     not rewritten: 4)."""
     O = C + P
-    scene_in = C * 40 + P * (48 + NV * 16 + 4 + 8)
+    scene_in = C * 40 + P * (48 + NV * 16 + 4 + 8 + 8)
     vessel_in = 48 + 64 + 2
     pos_out = O * 16
     lidar_out = R * 16
