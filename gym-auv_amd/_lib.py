@@ -22,7 +22,7 @@ F64, F32, I32, U8, I64 = 0, 1, 2, 3, 4
 (BUF_STATE, BUF_ACTION, BUF_RANGES, BUF_HIT, BUF_PERCEPTION, BUF_NAVIGATION,
  BUF_OBST_DIST, BUF_RISK, BUF_META, BUF_OWN, BUF_COLLISION, BUF_REACHED_GOAL,
  BUF_TRUNCATED, BUF_DONE, BUF_MIN_DIST, BUF_MIN_IDX, BUF_ALONG, BUF_T_STEP,
- BUF_CIRCLES, BUF_POLY_POSE, BUF_REWARD, BUF_CNN_OUT, BUF_EPISODE, BUF_COUNT) = range(24)
+ BUF_CIRCLES, BUF_POLY_POSE, BUF_REWARD, BUF_CNN_OUT, BUF_EPISODE, BUF_PATH_SEG, BUF_COUNT) = range(25)
 
 BUFFER_NAMES = {
     "state": BUF_STATE, "action": BUF_ACTION, "ranges": BUF_RANGES, "hit": BUF_HIT,
@@ -31,7 +31,7 @@ BUFFER_NAMES = {
     "reached_goal": BUF_REACHED_GOAL, "truncated": BUF_TRUNCATED, "done": BUF_DONE,
     "min_dist": BUF_MIN_DIST, "min_idx": BUF_MIN_IDX, "along": BUF_ALONG,
     "t_step": BUF_T_STEP, "circles": BUF_CIRCLES, "poly_pose": BUF_POLY_POSE,
-    "reward": BUF_REWARD, "cnn_out": BUF_CNN_OUT, "episode": BUF_EPISODE,
+    "reward": BUF_REWARD, "cnn_out": BUF_CNN_OUT, "episode": BUF_EPISODE, "path_seg": BUF_PATH_SEG,
 }
 
 # auv_option
@@ -57,7 +57,7 @@ EXPORTS = (
     "auv_profile_enable", "auv_cnn_n_weights", "auv_cnn_out_dim", "auv_cnn_create", "auv_cnn_destroy",
     "auv_cnn_forward", "auv_cnn_last_error", "auv_format_rows",
     "auv_profile_read", "auv_attach_cnn", "auv_generate_scene", "auv_host_alloc", "auv_host_free",
-    "auv_risk_rows", "auv_episode_stats", "auv_episode_stats_static", "auv_train_shallow",
+    "auv_risk_rows", "auv_episode_stats", "auv_episode_stats_static", "auv_train_shallow", "auv_set_path",
 )
 
 
@@ -65,7 +65,7 @@ class AuvConfig(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("n_envs", C.c_int32), ("n_rays", C.c_int32),
         ("n_circles", C.c_int32), ("n_polys", C.c_int32), ("n_verts", C.c_int32),
-        ("max_steps", C.c_int32), ("reserved", C.c_int32),
+        ("max_steps", C.c_int32), ("n_path_segments", C.c_int32),
         ("dt", C.c_double), ("sensor_range", C.c_double), ("vessel_radius", C.c_double),
         ("thrust_max", C.c_double), ("moment_max", C.c_double), ("look_ahead", C.c_double),
         ("goal_radius", C.c_double), ("risk", C.c_double * 3), ("reward", C.c_double * 4),
@@ -176,5 +176,7 @@ def load():
     lib.auv_episode_stats_static.argtypes = [vp, vp, i32, vp]
     lib.auv_train_shallow.restype = C.c_int
     lib.auv_train_shallow.argtypes = [C.c_int, vp, vp, i64, vp, i64, i32, vp, vp, C.POINTER(AuvTrainParams), i64, vp, vp]
+    lib.auv_set_path.restype = C.c_int
+    lib.auv_set_path.argtypes = [vp, i32, i32, vp, i32, vp]
     _lib = lib
     return lib

@@ -184,10 +184,59 @@ __global__ __launch_bounds__(256) void k_dynamics(DynArgs a) {
 
 // masked reset: vessel state, step counter, and the env's obstacles back to
 // the poses they were uploaded with
+// A path is a polyline of up to KS segments per env, one record of kPathRec
+// doubles each: x0, y0, angle, cos angle, sin angle, length, arc length before
+// the segment, 0.  A vessel is ON one segment (carried per env): when its
+// projection passes the end of that segment it moves on to the next, never
+// back.  Along-track position = arc length before the segment + projection on
+// it; cross-track and heading errors are those of the current segment; the
+// look-ahead point lies look_ahead further along the path, on the segment that
+// holds that arc length (the last one extended).  One segment reproduces the
+// straight-path arithmetic exactly (0 + x and x - 0 are exact).
+constexpr int kPathRec = 8;
+struct PathNav {
+    double along, cte, la, he, total;
+};
+struct PathRecord {
+    double x0, y0, angle, ca, sa, len, before;
+};
+__device__ __forceinline__ PathRecord load_path_record(const double* tab, int seg) {
+    const double* pt = tab + (size_t)seg * kPathRec;
+    return PathRecord{pt[0], pt[1], pt[2], pt[3], pt[4], pt[5], pt[6]};
+}
+// `cur` = the record of segment `seg` and `last` = the record of the last segment in use, both loaded by the
+// caller (k_vessel asks for them before its integration, whose length hides their latency)
+__device__ __forceinline__ PathNav path_navigation(const double* tab, int nseg, int& seg, PathRecord cur,
+                                                   const PathRecord& last, double px, double py, double psi,
+                                                   double look_ahead) {
+    double rx = px - cur.x0, ry = py - cur.y0;
+    double loc = rx * cur.ca + ry * cur.sa;
+    while (seg + 1 < nseg && loc > cur.len) {
+        ++seg;
+        cur = load_path_record(tab, seg);
+        rx = px - cur.x0;
+        ry = py - cur.y0;
+        loc = rx * cur.ca + ry * cur.sa;
+    }
+    PathNav n;
+    n.along = cur.before + loc;
+    n.cte = ry * cur.ca - rx * cur.sa;
+    const double st = n.along + look_ahead;
+    PathRecord pl = cur;
+    for (int j = seg; j + 1 < nseg && st > pl.before + pl.len; ++j) pl = load_path_record(tab, j + 1);
+    const double tx = pl.x0 + (st - pl.before) * pl.ca;
+    const double ty = pl.y0 + (st - pl.before) * pl.sa;
+    n.la = wrap_angle(atan2_det(ty - py, tx - px) - psi);
+    n.he = wrap_angle(cur.angle - psi);
+    n.total = last.before + last.len;
+    return n;
+}
+
 struct ResetArgs {
     Dims d;
     double* state;
     int32_t* t_step;
+    int32_t* path_seg;    // [V] back to the first segment
     const double* init;   // [6,V]
     const uint8_t* mask;  // [V] or null = all
     double* circles;
@@ -203,6 +252,7 @@ __global__ __launch_bounds__(256) void k_reset(ResetArgs a) {
     if (a.mask != nullptr && a.mask[i] == 0) return;
     for (int f = 0; f < 6; ++f) a.state[f * (size_t)V + i] = a.init[f * (size_t)V + i];
     a.t_step[i] = 0;
+    a.path_seg[i] = 0;
     const size_t c0 = (size_t)i * a.d.C * 5;
     for (int k = 0; k < a.d.C * 5; ++k) a.circles[c0 + k] = a.circles0[c0 + k];
     const size_t p0 = (size_t)i * a.d.P * 6;
@@ -222,7 +272,10 @@ struct EncArgs {
     const double* poly_verts;  // [V,P,NV,2]
     const int32_t* poly_nv;    // [V,P]
     const double* poly_heading;
-    const double* path;  // [V,6]
+    const double* path;  // [V,KS,kPathRec]
+    const int32_t* path_nseg;  // [V]
+    int32_t* path_seg;         // [V]
+    int KS;
     double* obst_dist;   // [V,O]
     double* risk;        // [V,O]
     double* meta;        // [V,O,5]
@@ -416,16 +469,13 @@ __global__ __launch_bounds__(256) void k_encounter(EncArgs a) {
         const double voy = sc.s * u + sc.c * v;
         a.own[2 * (size_t)e] = __builtin_sqrt(vox * vox + voy * voy);
         a.own[2 * (size_t)e + 1] = psi;
-        const double* pt = a.path + (size_t)e * 6;
-        const double x0 = pt[0], y0 = pt[1], ang = pt[2], ca = pt[3], sa = pt[4], len = pt[5];
-        const double rx = px - x0;
-        const double ry = py - y0;
-        const double al = rx * ca + ry * sa;
-        const double cte = ry * ca - rx * sa;
-        const double tx = x0 + (al + a.look_ahead) * ca;
-        const double ty = y0 + (al + a.look_ahead) * sa;
-        const double la = wrap_angle(atan2_det(ty - py, tx - px) - psi);
-        const double he = wrap_angle(ang - psi);
+        int seg = a.path_seg[e];
+        const double* tab = a.path + (size_t)e * a.KS * kPathRec;
+        const int nseg = a.path_nseg[e];
+        const PathNav pn = path_navigation(tab, nseg, seg, load_path_record(tab, seg), load_path_record(tab, nseg - 1), px,
+                                           py, psi, a.look_ahead);
+        a.path_seg[e] = seg;
+        const double al = pn.along, cte = pn.cte, la = pn.la, he = pn.he, len = pn.total;
         float* nav = a.navigation + (size_t)e * 6;
         nav[0] = (float)u;
         nav[1] = (float)v;

@@ -63,7 +63,9 @@ struct SceneGenArgs {
     double* poly_beam;
     double* poly_reach2;
     double* poly_rot;           // [V,P,NV,2]
-    double* path;  // [V,6]
+    double* path;  // [V,KS,kPathRec]: the generator lays one straight segment
+    int32_t* path_nseg;
+    int KS;
     double* init;  // [6,V]
     double extent, r_lo, r_hi, w_lo, w_hi, s_lo, s_hi, clearance, path_length;
     int size_law;  // 0: uniform; 1: whole-number sizes and speeds with a triangular law
@@ -102,13 +104,16 @@ __global__ __launch_bounds__(256) void k_scenegen(SceneGenArgs a) {
         const double psi = u.a * kTwoPi - kPi;
         const SinCos sc = sincos_det(psi);
         for (int f = 0; f < 6; ++f) a.init[(size_t)f * V + e] = f == 2 ? psi : 0.0;
-        double* pt = a.path + (size_t)e * 6;
+        double* pt = a.path + (size_t)e * a.KS * kPathRec;
         pt[0] = 0.0;
         pt[1] = 0.0;
         pt[2] = psi;
         pt[3] = sc.c;
         pt[4] = sc.s;
         pt[5] = a.path_length;
+        pt[6] = 0.0;
+        pt[7] = 0.0;
+        a.path_nseg[e] = 1;
     } else if (slot <= C) {
         const int j = slot - 1;
         const Uniform2 up = uniform2(a.seed, e, ep, SG_CIRCLE_POS, j);

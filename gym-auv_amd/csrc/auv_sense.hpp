@@ -47,7 +47,10 @@ struct VesselArgs {
     double* state;         // [6,V]
     const double* action;  // [2,V]
     int32_t* t_step;
-    const double* path;  // [V,6]
+    const double* path;  // [V,KS,kPathRec]
+    const int32_t* path_nseg;  // [V] segments in use
+    int32_t* path_seg;         // [V] the segment each vessel is on
+    int KS;
     double* envrec;      // [V,8]
     double* own;         // [V,2]
     double* along;       // [V]
@@ -90,6 +93,11 @@ __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
     for (int j = 0; j < 4; ++j)
         if ((int)threadIdx.x + j * nthr < n_items) held[j] = *item_src(threadIdx.x + j * nthr);
     if (live) {
+    // the path records this vessel will need, asked for ahead of the integration
+    const double* tab = a.path + (size_t)i * a.KS * kPathRec;
+    const int nseg = a.path_nseg[i];
+    int seg = restart ? 0 : a.path_seg[i];
+    const PathRecord cur = load_path_record(tab, seg), last = load_path_record(tab, nseg - 1);
     Vec6 s = load_state(a.state, V, i);
     int t = a.t_step[i];
     if (a.do_step) {
@@ -109,16 +117,9 @@ __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
     const double voy = sc.s * s.u + sc.c * s.v;
     a.own[2 * (size_t)i] = __builtin_sqrt(vox * vox + voy * voy);
     a.own[2 * (size_t)i + 1] = s.psi;
-    const double* pt = a.path + (size_t)i * 6;
-    const double x0 = pt[0], y0 = pt[1], ang = pt[2], ca = pt[3], sa = pt[4], len = pt[5];
-    const double rx = s.x - x0;
-    const double ry = s.y - y0;
-    const double al = rx * ca + ry * sa;
-    const double cte = ry * ca - rx * sa;
-    const double tx = x0 + (al + a.look_ahead) * ca;
-    const double ty = y0 + (al + a.look_ahead) * sa;
-    const double la = wrap_angle(atan2_det(ty - s.y, tx - s.x) - s.psi);
-    const double he = wrap_angle(ang - s.psi);
+    const PathNav pn = path_navigation(tab, nseg, seg, cur, last, s.x, s.y, s.psi, a.look_ahead);
+    a.path_seg[i] = seg;
+    const double al = pn.along, cte = pn.cte, la = pn.la, he = pn.he, len = pn.total;
     float* nav = a.navigation + (size_t)i * 6;
     nav[0] = (float)s.u;
     nav[1] = (float)s.v;

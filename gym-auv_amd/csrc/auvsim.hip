@@ -92,7 +92,9 @@ struct auv_sim {
     double* poly_beam = nullptr;  // [V,P] extent of the body-frame vertices across the heading (a scene constant)
     double* poly_reach2 = nullptr;  // [V,P] squared distance of the farthest vertex from the pose point, -1 unless the
                                     // polygon is strictly convex and counter-clockwise (polygon_reach2; a scene constant)
-    double* path = nullptr;
+    double* path = nullptr;        // [V,KS,kPathRec] segment records of every env's path
+    int32_t* path_nseg = nullptr;  // [V] segments in use
+    int KS = 1;                    // segment slots per path
     double* ray_dirs = nullptr;
     double* init_stage = nullptr;  // [6,V] staging for reset
     double* circles0 = nullptr;    // obstacle poses as uploaded (restored on reset)
@@ -266,6 +268,8 @@ int launch_scenegen(auv_sim* h, hipStream_t st, const uint8_t* only_done) {
     ga.poly_reach2 = h->poly_reach2;
     ga.poly_rot = h->poly_rot;
     ga.path = h->path;
+    ga.path_nseg = h->path_nseg;
+    ga.KS = h->KS;
     ga.init = h->init_stage;
     const auv_scene_params& p = h->gen_params;
     ga.extent = p.extent;
@@ -331,6 +335,9 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     va.action = action;
     va.t_step = bp<int32_t>(h, AUV_BUF_T_STEP);
     va.path = h->path;
+    va.path_nseg = h->path_nseg;
+    va.path_seg = bp<int32_t>(h, AUV_BUF_PATH_SEG);
+    va.KS = h->KS;
     va.envrec = h->envrec;
     va.own = bp<double>(h, AUV_BUF_OWN);
     va.along = bp<double>(h, AUV_BUF_ALONG);
@@ -441,6 +448,9 @@ int launch_sense(auv_sim* h, hipStream_t st, hipEvent_t* ev, int is_step) {
     ea.poly_nv = h->poly_nv;
     ea.poly_heading = h->poly_heading;
     ea.path = h->path;
+    ea.path_nseg = h->path_nseg;
+    ea.path_seg = bp<int32_t>(h, AUV_BUF_PATH_SEG);
+    ea.KS = h->KS;
     ea.obst_dist = bp<double>(h, AUV_BUF_OBST_DIST);
     ea.risk = bp<double>(h, AUV_BUF_RISK);
     ea.meta = bp<double>(h, AUV_BUF_META);
@@ -518,6 +528,34 @@ int launch_stats(auv_sim* h, double* records, double* out, int accumulate, hipSt
     HIP_TRY(h, hipGetLastError());
     hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(kStatsThreads), 0, st, records, blocks, out, accumulate);
     HIP_TRY(h, hipGetLastError());
+    return AUV_OK;
+}
+
+// Segment records of envs [env_begin, env_begin + env_count): `segments` is host f64 [n, ks, 6] = x0, y0, angle,
+// cos, sin, length per segment (ks <= KS slots), `n_segments` host i32 [n] or null (= ks everywhere).  The
+// arc length before each segment is summed here, in segment order.
+int upload_path(auv_sim* h, int32_t env_begin, int32_t env_count, const double* segments, int ks, const int32_t* n_segments) {
+    const size_t n = (size_t)env_count, KS = (size_t)h->KS;
+    std::vector<double> tab(n * KS * kPathRec, 0.0);
+    std::vector<int32_t> cnt(n, ks);
+    for (size_t i = 0; i < n; ++i) {
+        if (n_segments) {
+            if (n_segments[i] < 1 || n_segments[i] > ks)
+                return fail(h, AUV_ERR_ARG, "path of env %zu has %d segments, expected 1..%d", (size_t)env_begin + i, n_segments[i], ks);
+            cnt[i] = n_segments[i];
+        }
+        double cum = 0.0;
+        for (int k = 0; k < ks; ++k) {
+            const double* src = segments + (i * (size_t)ks + k) * 6;
+            double* dst = &tab[(i * KS + k) * kPathRec];
+            for (int f = 0; f < 6; ++f) dst[f] = src[f];
+            dst[6] = cum;
+            cum = cum + src[5];
+        }
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(h->path + (size_t)env_begin * KS * kPathRec, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->path_nseg + env_begin, cnt.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
     return AUV_OK;
 }
 
@@ -611,6 +649,8 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     if ((long long)cfg->n_envs * cfg->n_rays > (1ll << 31) - 1 ||
         (long long)cfg->n_envs * (cfg->n_circles + cfg->n_polys) > (1ll << 31) - 1)
         return fail(nullptr, AUV_ERR_ARG, "auv_create: batch too large for 32-bit ray/obstacle indices");
+    if (cfg->n_path_segments < 0 || cfg->n_path_segments > 4096)
+        return fail(nullptr, AUV_ERR_ARG, "auv_create: n_path_segments must be in 0..4096");
     if (!(cfg->dt > 0.0) || !(cfg->sensor_range > 0.0))
         return fail(nullptr, AUV_ERR_ARG, "auv_create: dt and sensor_range must be positive");
     int n_dev = 0;
@@ -637,6 +677,7 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     d.P = cfg->n_polys;
     d.NV = cfg->n_polys > 0 ? cfg->n_verts : 1;
     d.O = d.C + d.P;
+    h->KS = cfg->n_path_segments > 0 ? cfg->n_path_segments : 1;
     choose_geometry(h);
     // dynamic LDS beyond the 64 KiB default window has to be granted per kernel
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sense<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -688,7 +729,9 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     chk(alloc_raw(h, &h->poly_heading, (size_t)V * P));
     chk(alloc_raw(h, &h->poly_beam, (size_t)V * P));
     chk(alloc_raw(h, &h->poly_reach2, (size_t)V * P));
-    chk(alloc_raw(h, &h->path, (size_t)V * 6));
+    chk(alloc_raw(h, &h->path, (size_t)V * h->KS * kPathRec));
+    chk(alloc_raw(h, &h->path_nseg, (size_t)V));
+    chk(alloc_buf(h, AUV_BUF_PATH_SEG, AUV_I32, {V}));
     chk(alloc_raw(h, &h->ray_dirs, (size_t)R * 2));
     chk(alloc_raw(h, &h->init_stage, (size_t)V * 6));
     chk(alloc_raw(h, &h->circles0, (size_t)V * C * 5));
@@ -705,9 +748,11 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     // default path: along +x from the origin (cos = 1), so navigation is defined
     // even when the caller never uploads paths
     {
-        std::vector<double> p((size_t)V * 6, 0.0);
-        for (int64_t i = 0; i < V; ++i) p[(size_t)i * 6 + 3] = 1.0;
-        if (hipMemcpy(h->path, p.data(), p.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        std::vector<double> p((size_t)V * h->KS * kPathRec, 0.0);
+        std::vector<int32_t> one((size_t)V, 1);
+        for (int64_t i = 0; i < V; ++i) p[(size_t)i * h->KS * kPathRec + 3] = 1.0;
+        if (hipMemcpy(h->path, p.data(), p.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->path_nseg, one.data(), one.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
             auv_destroy(h);
             return fail(nullptr, AUV_ERR_DEVICE, "auv_create: path upload failed");
         }
@@ -723,7 +768,7 @@ void auv_destroy(auv_handle h) {
     for (auto& ev : h->events) (void)hipEventDestroy(ev);
     for (auto& b : h->buf)
         if (b.ptr) (void)hipFree(b.ptr);
-    void* raw[] = {h->poly_verts, h->poly_rot, h->poly_nv, h->poly_heading, h->poly_beam, h->poly_reach2, h->path, h->ray_dirs, h->init_stage, h->mask_stage,
+    void* raw[] = {h->poly_verts, h->poly_rot, h->poly_nv, h->poly_heading, h->poly_beam, h->poly_reach2, h->path, h->path_nseg, h->ray_dirs, h->init_stage, h->mask_stage,
                    h->circles0, h->poly_pose0, h->envrec, h->cnn_w, h->stats_ws};
     for (void* p : raw)
         if (p) (void)hipFree(p);
@@ -815,13 +860,28 @@ int auv_set_scene(auv_handle h, int32_t env_begin, int32_t env_count, const doub
         }
         HIP_TRY(h, hipMemcpy(h->poly_rot + b * d.P * d.NV * 2, rot.data(), rot.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    if (path) HIP_TRY(h, hipMemcpy(h->path + b * 6, path, n * 6 * sizeof(double), hipMemcpyHostToDevice));
+    if (path) {
+        int rc = upload_path(h, env_begin, env_count, path, 1, nullptr);  // one straight segment per env
+        if (rc) return rc;
+    }
     // the scene is complete once the calls so far have covered [0, V): each call may extend the covered
     // prefix (or rewrite envs inside it)
     h->heading_stale = true;
     if (env_begin <= h->scene_upto && env_begin + env_count > h->scene_upto) h->scene_upto = env_begin + env_count;
     if (h->scene_upto == d.V) h->have_scene = true;
     return AUV_OK;
+}
+
+int auv_set_path(auv_handle h, int32_t env_begin, int32_t env_count, const double* segments, int32_t n_slots,
+                 const int32_t* n_segments) {
+    if (!h) return AUV_ERR_ARG;
+    if (!segments) return fail(h, AUV_ERR_ARG, "auv_set_path: segments is NULL");
+    if (env_begin < 0 || env_count < 1 || (long long)env_begin + env_count > h->d.V)
+        return fail(h, AUV_ERR_ARG, "auv_set_path: env range [%d,%d) outside [0,%d)", env_begin, env_begin + env_count, h->d.V);
+    if (n_slots < 1 || n_slots > h->KS)
+        return fail(h, AUV_ERR_ARG, "auv_set_path: %d segments per env, the batch was created with room for %d "
+                    "(auv_config.n_path_segments)", n_slots, h->KS);
+    return upload_path(h, env_begin, env_count, segments, n_slots, n_segments);
 }
 
 int auv_generate_scene(auv_handle h, uint64_t seed, const auv_scene_params* params, void* stream) {
@@ -868,6 +928,7 @@ int auv_reset(auv_handle h, const uint8_t* mask, const double* init_state, void*
     ra.d = d;
     ra.state = bp<double>(h, AUV_BUF_STATE);
     ra.t_step = bp<int32_t>(h, AUV_BUF_T_STEP);
+    ra.path_seg = bp<int32_t>(h, AUV_BUF_PATH_SEG);
     ra.init = h->init_stage;
     ra.mask = mask ? h->mask_stage : nullptr;
     ra.circles = bp<double>(h, AUV_BUF_CIRCLES);

@@ -53,6 +53,21 @@ def _straight_path(V, angle, length=800.0):
     return path
 
 
+def waypoint_path(points, n_points=None):
+    """Segment records [V,K-1,6] = (x0, y0, angle, cos, sin, length) of the
+    polylines through `points` [V,K,2] (what `AuvSim.set_path` and the oracles'
+    `set_path` take), and the number of segments in use per env ([V]; from
+    `n_points` [V] waypoints in use, default all K)."""
+    pts = np.asarray(points, dtype=np.float64)
+    d = pts[:, 1:] - pts[:, :-1]
+    length = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1])
+    safe = np.where(length > 0.0, length, 1.0)
+    ca, sa = d[..., 0] / safe, d[..., 1] / safe
+    seg = np.stack([pts[:, :-1, 0], pts[:, :-1, 1], np.arctan2(d[..., 1], d[..., 0]), ca, sa, length], axis=-1)
+    n = np.full(len(pts), pts.shape[1] - 1, dtype=np.int32) if n_points is None else np.asarray(n_points, dtype=np.int32) - 1
+    return np.ascontiguousarray(seg), n
+
+
 def _moving_polys(rng, V, P, NV, extent, width_lo, width_hi, speed_lo, speed_hi, n_sides=None):
     X = rng.uniform(-extent, extent, (V, P))
     Y = rng.uniform(-extent, extent, (V, P))

@@ -57,6 +57,7 @@ class AuvSim:
         c.abi_version = _lib.ABI_VERSION
         for k in ("n_envs", "n_rays", "n_circles", "n_polys", "n_verts", "max_steps"):
             setattr(c, k, int(cfg[k]))
+        c.n_path_segments = int(cfg.get("n_path_segments", 1))
         for k in ("dt", "sensor_range", "vessel_radius", "thrust_max", "moment_max",
                   "look_ahead", "goal_radius"):
             setattr(c, k, float(cfg[k]))
@@ -113,9 +114,25 @@ class AuvSim:
             head = _f64(scene.get("poly_heading", np.zeros((n, self.P))), (n, self.P))
         else:
             pose = verts = nv = head = None
-        path = _f64(scene["path"], (n, 6)) if scene.get("path") is not None else None
+        path = scene.get("path")
+        polyline = path is not None and np.asarray(path).ndim == 3
+        straight = _f64(path, (n, 6)) if path is not None and not polyline else None
         self._check(self._lib.auv_set_scene(self._h, int(env_begin), n, _ptr(circles), _ptr(pose),
-                                            _ptr(verts), _ptr(nv), _ptr(head), _ptr(path)))
+                                            _ptr(verts), _ptr(nv), _ptr(head), _ptr(straight)))
+        if polyline:
+            self.set_path(path, scene.get("path_nseg"), env_begin)
+
+    def set_path(self, segments, n_segments=None, env_begin: int = 0):
+        """Polyline paths [n,KS,6] = (x0, y0, angle, cos, sin, length) per segment
+        (`scenarios.waypoint_path` makes them from waypoints), `n_segments` [n]
+        in use per env (None: all); cfg["n_path_segments"] must cover KS."""
+        seg = np.ascontiguousarray(segments, dtype=np.float64)
+        if seg.ndim != 3 or seg.shape[2] != 6:
+            raise ValueError("segments must be [n,KS,6]")
+        cnt = None if n_segments is None else np.ascontiguousarray(n_segments, dtype=np.int32)
+        if cnt is not None and cnt.shape != (seg.shape[0],):
+            raise ValueError("n_segments shape")
+        self._check(self._lib.auv_set_path(self._h, int(env_begin), seg.shape[0], _ptr(seg), seg.shape[1], _ptr(cnt)))
 
     def generate_scene(self, seed: int, params: dict | None = None, stream=None):
         """Scene, paths and initial states of every env from the device-side

@@ -58,7 +58,7 @@ typedef struct auv_config {
     int32_t n_polys;        /* P  polygon slots per env */
     int32_t n_verts;        /* NV vertex slots per polygon (3..16) */
     int32_t max_steps;      /* truncation horizon */
-    int32_t reserved;
+    int32_t n_path_segments; /* segment slots per path (0 or 1: straight paths; more: polylines, auv_set_path) */
     double dt;              /* integrator step, s */
     double sensor_range;    /* 150 m: utils/dataloader.py:56 */
     double vessel_radius;   /* clearance taken off every obstacle distance, m (3.255: what the reference's logged
@@ -104,7 +104,8 @@ typedef enum auv_buffer {
     AUV_BUF_REWARD = 20,     /* f64 [V]   reward of the last step (0 after reset) */
     AUV_BUF_CNN_OUT = 21,    /* f32 [V,out_dim] output of the attached network (auv_attach_cnn); zeros, out_dim 12, before */
     AUV_BUF_EPISODE = 22,    /* i32 [V]   in-step restarts of the env so far (= its episode number for the generator) */
-    AUV_BUF_COUNT = 23
+    AUV_BUF_PATH_SEG = 23,   /* i32 [V]   the segment of its path each vessel is on */
+    AUV_BUF_COUNT = 24
 } auv_buffer;
 
 /* Tunables (auv_set_option).  Both LiDAR kernels produce identical bits; the
@@ -182,6 +183,20 @@ int auv_set_scene(auv_handle h, int32_t env_begin, int32_t env_count,
                   const double* circles, const double* poly_pose,
                   const double* poly_verts, const int32_t* poly_nv,
                   const double* poly_heading, const double* path);
+
+/* Piecewise-straight paths for envs [env_begin, env_begin+env_count): host f64
+ * segments [n, n_slots, 6] = x0, y0, angle, cos angle, sin angle, length per
+ * segment (n_slots <= auv_config.n_path_segments), host i32 n_segments [n]
+ * segments in use per env or NULL (= n_slots).  A vessel is on one segment
+ * (AUV_BUF_PATH_SEG; the first after a reset) and moves on to the next when its
+ * projection passes the segment's end, never back.  The navigation features
+ * (the 6 numbers of obs["navigation"], radarCNN.py:184-193) are then: along-track
+ * position = arc length before the segment + projection on it; cross-track and
+ * heading errors of the current segment; look-ahead heading error towards the
+ * point look_ahead further along the path.  The goal is the end of the last
+ * segment.  auv_set_scene's `path` is the one-segment case. */
+int auv_set_path(auv_handle h, int32_t env_begin, int32_t env_count, const double* segments, int32_t n_slots,
+                 const int32_t* n_segments);
 
 /* Parameters of the scenario generator (metres, m/s). */
 typedef struct auv_scene_params {

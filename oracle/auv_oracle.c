@@ -53,7 +53,7 @@ enum { MP_MINV11, MP_MINV22, MP_MINV23, MP_MINV32, MP_MINV33, MP_MU, MP_MXG, MP_
 
 typedef struct {
     int32_t V, R, C, P, NV, max_steps;
-    int32_t risk_model, pad_;   /* 0: closest-point-of-approach index, 1: oc_risk_reference */
+    int32_t risk_model, KS;     /* 0: closest-point-of-approach index, 1: oc_risk_reference; KS: segment slots per path */
     double dt, sensor_range, vessel_radius, thrust_max, moment_max, look_ahead, goal_radius;
     double risk[3], reward[4], model[16];
 } oc_config;
@@ -71,6 +71,8 @@ typedef struct {
     double *ranges; int32_t *hit; float *perception; double *obst_dist; uint8_t *collision;
     double *min_dist; int32_t *min_idx; double *own, *meta, *risk; float *navigation;
     uint8_t *reached_goal, *truncated, *done; double *reward;
+    const int32_t *path_nseg;   /* [V] segments in use; path is [V,KS,8] = x0,y0,angle,cos,sin,length,arc length before,0 */
+    int32_t *path_seg;          /* [V] the segment each vessel is on (in/out) */
 } oc_buffers;
 
 /* oracle/ref_cri.py: bearing_membership, cri_core, risk_reference -- the
@@ -429,21 +431,38 @@ static void oc_sense_env(const oc_config *cf, const oc_buffers *b, int e, int is
             ? oc_risk_reference(mx, my, vx, vy, vox, voy, dref, c, s, psi, dref < INFINITY) : (inrange ? rr : 0.0);
     }
 
-    /* navigation, flags, reward */
-    const double *pt = b->path + (size_t)e * 6;
-    const double rx = px - pt[0], ry = py - pt[1];
-    const double along = rx * pt[3] + ry * pt[4];
+    /* navigation, flags, reward (oracle/auv_oracle.py: navigation_features) */
+    const int KS = cf->KS > 0 ? cf->KS : 1;
+    const double *tab = b->path + (size_t)e * KS * 8;
+    const int nseg = b->path_nseg[e];
+    int seg = b->path_seg[e];
+    const double *pt = tab + (size_t)seg * 8;
+    double rx = px - pt[0], ry = py - pt[1];
+    double loc = rx * pt[3] + ry * pt[4];
+    while (seg + 1 < nseg && loc > pt[5]) {   /* past the end of its segment: on to the next one, never back */
+        ++seg;
+        pt += 8;
+        rx = px - pt[0];
+        ry = py - pt[1];
+        loc = rx * pt[3] + ry * pt[4];
+    }
+    b->path_seg[e] = seg;
+    const double along = pt[6] + loc;
     const double cte = ry * pt[3] - rx * pt[4];
-    const double tx = pt[0] + (along + cf->look_ahead) * pt[3];
-    const double ty = pt[1] + (along + cf->look_ahead) * pt[4];
+    const double st = along + cf->look_ahead;
+    const double *pl = pt;
+    for (int j = seg; j + 1 < nseg && st > pl[6] + pl[5]; ++j) pl += 8;
+    const double tx = pl[0] + (st - pl[6]) * pl[3];
+    const double ty = pl[1] + (st - pl[6]) * pl[4];
     const double la = oc_wrap(oc_atan2(ty - py, tx - px) - psi);
     const double he = oc_wrap(pt[2] - psi);
+    const double total = tab[(size_t)(nseg - 1) * 8 + 6] + tab[(size_t)(nseg - 1) * 8 + 5];
     float *nav = b->navigation + (size_t)e * 6;
     nav[0] = (float)u; nav[1] = (float)v; nav[2] = (float)r;
     nav[3] = (float)la; nav[4] = (float)he; nav[5] = (float)cte;
     const double prev_along = b->along[e];
     b->along[e] = along;
-    const uint8_t goal = (pt[5] - along) <= cf->goal_radius;
+    const uint8_t goal = (total - along) <= cf->goal_radius;
     const uint8_t trunc = b->t_step[e] >= cf->max_steps;
     b->reached_goal[e] = goal;
     b->truncated[e] = trunc;

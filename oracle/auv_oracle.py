@@ -499,23 +499,81 @@ def risk_default(state, circles, poly_pose, dist, sensor_range, rp):
 # ----------------------------------------------------------------------------
 # a7: observation assembly
 # ----------------------------------------------------------------------------
-def navigation_features(state, path, look_ahead):
+def path_table(path, nseg=None):
+    """Segment table [V,KS,8] = (x0, y0, angle, cos, sin, length, arc length
+    before the segment, 0) and segment counts [V] of a path given as one
+    straight segment per env [V,6] or as a polyline [V,KS,6] with `nseg`
+    segments in use per env (None: all KS)."""
+    path = np.asarray(path, dtype=np.float64)
+    if path.ndim == 2:
+        path = path[:, None, :]
+    V, KS = path.shape[:2]
+    tab = np.zeros((V, KS, 8))
+    tab[:, :, :6] = path
+    cum = np.zeros(V)
+    for k in range(KS):
+        tab[:, k, 6] = cum
+        cum = cum + path[:, k, 5]
+    n = np.full(V, KS, dtype=np.int32) if nseg is None else np.asarray(nseg, dtype=np.int32).copy()
+    return tab, n
+
+
+def navigation_features(state, path, look_ahead, nseg=None, seg=None):
     """[u, v, r, look-ahead heading error, heading error, cross-track error]
-    with respect to a straight path per env; path [V,6] =
-    (x0, y0, angle, cos angle, sin angle, length).  Also returns along-track
-    position s [V]."""
+    with respect to a path per env: one straight segment [V,6] = (x0, y0,
+    angle, cos angle, sin angle, length), or a segment table [V,KS,8] of
+    `path_table` with `nseg` segments in use and `seg` [V] the segment each
+    vessel is on (updated in place: a vessel whose projection has passed the end
+    of its segment moves on to the next one, never back).  Along-track
+    position = arc length before the segment + projection on it; cross-track
+    and heading errors are those of the current segment; the look-ahead point
+    lies `look_ahead` further along the path, on the segment that holds that arc
+    length (the last one extended).  Also returns the along-track position [V]
+    and the path's total length [V]."""
     px, py, psi = state[0], state[1], state[2]
-    x0, y0, ang, ca, sa = path[:, 0], path[:, 1], path[:, 2], path[:, 3], path[:, 4]
-    rx = px - x0
-    ry = py - y0
-    along = rx * ca + ry * sa
-    cte = ry * ca - rx * sa
-    tx = x0 + (along + look_ahead) * ca
-    ty = y0 + (along + look_ahead) * sa
+    path = np.asarray(path)
+    if path.ndim == 2:
+        path, nseg = path_table(path)
+    V, KS = path.shape[:2]
+    if seg is None:
+        seg = np.zeros(V, dtype=np.int32)
+    rows = np.arange(V)
+
+    def rec(j):
+        return path[rows, j]
+
+    pt = rec(seg)
+    rx = px - pt[:, 0]
+    ry = py - pt[:, 1]
+    loc = rx * pt[:, 3] + ry * pt[:, 4]
+    for _ in range(KS - 1):
+        go = (seg + 1 < nseg) & (loc > pt[:, 5])
+        if not go.any():
+            break
+        seg[go] += 1
+        pt = rec(seg)
+        rx = px - pt[:, 0]
+        ry = py - pt[:, 1]
+        loc = rx * pt[:, 3] + ry * pt[:, 4]
+    along = pt[:, 6] + loc
+    cte = ry * pt[:, 3] - rx * pt[:, 4]
+    st = along + look_ahead
+    j = seg.copy()
+    pl = pt
+    for _ in range(KS - 1):
+        go = (j + 1 < nseg) & (st > pl[:, 6] + pl[:, 5])
+        if not go.any():
+            break
+        j[go] += 1
+        pl = rec(j)
+    tx = pl[:, 0] + (st - pl[:, 6]) * pl[:, 3]
+    ty = pl[:, 1] + (st - pl[:, 6]) * pl[:, 4]
     la = wrap_angle(atan2(ty - py, tx - px) - psi)
-    he = wrap_angle(ang - psi)
+    he = wrap_angle(pt[:, 2] - psi)
+    last = rec(nseg - 1)
+    total = last[:, 6] + last[:, 5]
     nav = np.stack([state[3], state[4], state[5], la, he, cte], axis=1)
-    return nav, along
+    return nav, along, total
 
 
 def closeness(ranges, sensor_range):
@@ -536,8 +594,9 @@ class OracleEnv:
         V = cfg["n_envs"]
         self.state = np.zeros((6, V))
         self.t_step = np.zeros(V, dtype=np.int32)
-        self.path = np.zeros((V, 6))
-        self.path[:, 3] = 1.0
+        straight = np.zeros((V, 6))
+        straight[:, 3] = 1.0
+        self.set_path(straight)
         # in-step restart: an env whose done flag is set is reset by the next
         # step() instead of being integrated (reward 0, action ignored)
         self.auto_reset = False
@@ -559,8 +618,10 @@ class OracleEnv:
         self.circles0 = self.circles.copy()
         self.poly_pose0 = self.poly_pose.copy()
 
-    def set_path(self, path):
-        self.path = np.array(path, dtype=np.float64, copy=True)
+    def set_path(self, path, nseg=None):
+        """One straight segment per env [V,6], or a polyline [V,KS,6] with `nseg` [V] segments in use."""
+        self.path, self.path_nseg = path_table(path, nseg)
+        self.path_seg = np.zeros(self.path.shape[0], dtype=np.int32)
 
     def generate_scene(self, seed, params=None, env_ids=None):
         """Scene, paths and initial states of every env from the generator, episode 0.
@@ -586,12 +647,14 @@ class OracleEnv:
         if mask is None:
             self.state = init_state.copy()
             self.t_step[:] = 0
+            self.path_seg[:] = 0
             self.circles = self.circles0.copy()
             self.poly_pose = self.poly_pose0.copy()
         else:
             m = np.asarray(mask).astype(bool)
             self.state[:, m] = init_state[:, m]
             self.t_step[m] = 0
+            self.path_seg[m] = 0
             self.circles[m] = self.circles0[m]
             self.poly_pose[m] = self.poly_pose0[m]
         self.sense()
@@ -620,9 +683,10 @@ class OracleEnv:
                                      R, cfg["risk"])
         self.perception = closeness(self.ranges, R)
         prev_along = getattr(self, "along", None)
-        nav, self.along = navigation_features(self.state, self.path, cfg["look_ahead"])
+        nav, self.along, total = navigation_features(self.state, self.path, cfg["look_ahead"], self.path_nseg,
+                                                     self.path_seg)
         self.navigation = nav.astype(np.float32)[:, None, :]
-        self.reached_goal = ((self.path[:, 5] - self.along) <= cfg["goal_radius"]).astype(np.uint8)
+        self.reached_goal = ((total - self.along) <= cfg["goal_radius"]).astype(np.uint8)
         self.truncated = (self.t_step >= cfg["max_steps"]).astype(np.uint8)
         self.done = (self.collision | self.reached_goal | self.truncated).astype(np.uint8)
         if is_step:
@@ -655,10 +719,13 @@ class OracleEnv:
                 self.poly_verts[restart] = sc["poly_verts"]
                 self.poly_nv[restart] = sc["poly_nv"]
                 self.poly_heading[restart] = sc["poly_heading"]
-                self.path[restart] = sc["path"]
+                self.path[restart, 0, :6] = sc["path"]
+                self.path[restart, 0, 6] = 0.0
+                self.path_nseg[restart] = 1
                 self.init0[:, restart] = sc["init_state"]
             self.state[:, restart] = self.init0[:, restart]
             self.t_step[restart] = 0
+            self.path_seg[restart] = 0
             self.circles[restart] = self.circles0[restart]
             self.poly_pose[restart] = self.poly_pose0[restart]
         self.sense(is_step=True)

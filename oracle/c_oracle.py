@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "l
 
 class OcConfig(C.Structure):
     _fields_ = [("V", C.c_int32), ("R", C.c_int32), ("C", C.c_int32), ("P", C.c_int32), ("NV", C.c_int32),
-                ("max_steps", C.c_int32), ("risk_model", C.c_int32), ("pad_", C.c_int32),
+                ("max_steps", C.c_int32), ("risk_model", C.c_int32), ("KS", C.c_int32),
                 ("dt", C.c_double), ("sensor_range", C.c_double), ("vessel_radius", C.c_double),
                 ("thrust_max", C.c_double), ("moment_max", C.c_double), ("look_ahead", C.c_double),
                 ("goal_radius", C.c_double), ("risk", C.c_double * 3), ("reward", C.c_double * 4),
@@ -27,7 +27,7 @@ class OcConfig(C.Structure):
 
 _BUFS = ("state", "t_step", "circles", "poly_pose", "poly_verts", "poly_heading", "path", "ray_dirs", "poly_nv",
          "along", "ranges", "hit", "perception", "obst_dist", "collision", "min_dist", "min_idx", "own", "meta",
-         "risk", "navigation", "reached_goal", "truncated", "done", "reward")
+         "risk", "navigation", "reached_goal", "truncated", "done", "reward", "path_nseg", "path_seg")
 
 
 class OcBuffers(C.Structure):
@@ -76,8 +76,9 @@ class COracleEnv:
         self.ray_dirs = np.ascontiguousarray(ray_dirs, dtype=f8)
         self.state = np.zeros((6, V), f8)
         self.t_step = np.zeros(V, i4)
-        self.path = np.zeros((V, 6), f8)
-        self.path[:, 3] = 1.0
+        straight = np.zeros((V, 6), f8)
+        straight[:, 3] = 1.0
+        self.set_path(straight)
         self.circles = np.zeros((V, Cn, 5), f8)
         self.poly_pose = np.zeros((V, P, 6), f8)
         self.poly_verts = np.zeros((V, P, NV, 2), f8)
@@ -131,8 +132,23 @@ class COracleEnv:
         self.circles0 = self.circles.copy()
         self.poly_pose0 = self.poly_pose.copy()
 
-    def set_path(self, path):
-        self.path[...] = path
+    def set_path(self, path, nseg=None):
+        """One straight segment per env [V,6], or a polyline [V,KS,6] with `nseg` [V] segments in use; the
+        library reads the table [V,KS,8] = (x0, y0, angle, cos, sin, length, arc length before, 0)."""
+        path = np.asarray(path, dtype=np.float64)
+        if path.ndim == 2:
+            path = path[:, None, :]
+        V, KS = path.shape[:2]
+        tab = np.zeros((V, KS, 8))
+        tab[:, :, :6] = path
+        cum = np.zeros(V)
+        for k in range(KS):
+            tab[:, k, 6] = cum
+            cum = cum + path[:, k, 5]
+        self.path = np.ascontiguousarray(tab)
+        self.path_nseg = np.full(V, KS, dtype=np.int32) if nseg is None else np.ascontiguousarray(nseg, dtype=np.int32)
+        self.path_seg = np.zeros(V, dtype=np.int32)
+        self._c.KS = KS
 
     def reset(self, init_state, mask=None):
         init_state = np.asarray(init_state, dtype=np.float64)
@@ -142,6 +158,7 @@ class COracleEnv:
             m = np.asarray(mask).astype(bool)
         self.state[:, m] = init_state[:, m]
         self.t_step[m] = 0
+        self.path_seg[m] = 0
         self.circles[m] = self.circles0[m]
         self.poly_pose[m] = self.poly_pose0[m]
         self._run(None)

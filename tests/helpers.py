@@ -13,7 +13,7 @@ PAIRS = {
     "own": "own", "collision": "collision", "reached_goal": "reached_goal",
     "truncated": "truncated", "done": "done", "min_dist": "min_dist", "min_idx": "min_idx",
     "along": "along", "t_step": "t_step", "circles": "circles", "poly_pose": "poly_pose",
-    "reward": "reward", "episode": "episode",
+    "reward": "reward", "episode": "episode", "path_seg": "path_seg",
 }
 
 
@@ -21,7 +21,7 @@ def make_oracle(cfg, scene):
     env = O.OracleEnv(cfg, params.ray_table(cfg["n_rays"]))
     env.set_scene(scene["circles"], scene["poly_pose"], scene["poly_verts"], scene["poly_nv"],
                   scene.get("poly_heading"))
-    env.set_path(scene["path"])
+    env.set_path(scene["path"], scene.get("path_nseg"))
     return env
 
 
@@ -81,3 +81,21 @@ def risk_edge_case_scene(V=64):
     p[2::3, 1, 4:6] = (-0.5, -1e-300)        # and a hair over -pi
     scene["path"][:, 2] = init[2]
     return cfg, scene
+
+
+def winding_paths(V, K=5, seed=0, leg=(8.0, 30.0), turn=1.2):
+    """Polyline paths from the origin: K waypoints per env, legs of random length, each turning by up to `turn`
+    rad from the last; a third of the envs use fewer waypoints.  Returns (segments [V,K-1,6], n_segments [V],
+    initial heading [V] = direction of the first leg)."""
+    from gym_auv_amd import scenarios
+
+    rng = np.random.default_rng(seed)
+    ang = np.cumsum(np.concatenate([rng.uniform(-np.pi, np.pi, (V, 1)), rng.uniform(-turn, turn, (V, K - 2))], axis=1),
+                    axis=1)
+    length = rng.uniform(leg[0], leg[1], (V, K - 1))
+    pts = np.zeros((V, K, 2))
+    pts[:, 1:, 0] = np.cumsum(length * np.cos(ang), axis=1)
+    pts[:, 1:, 1] = np.cumsum(length * np.sin(ang), axis=1)
+    n_pts = np.where(np.arange(V) % 3 == 0, rng.integers(2, K + 1, V), K)
+    seg, nseg = scenarios.waypoint_path(pts, n_pts)
+    return seg, nseg, ang[:, 0]

@@ -83,3 +83,53 @@ def test_c_oracle_empty_scene_and_dense_scan():
         env.step(a[k])
         cenv.step(a[k])
     _check(env, cenv, "cfg5")
+
+
+def test_polyline_paths_c_equals_numpy_and_vessels_round_the_corners():
+    from tests.helpers import make_oracle, winding_paths
+
+    V = 90
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=V)
+    seg, nseg, psi0 = winding_paths(V, K=5, seed=3)
+    scene["path"], scene["path_nseg"] = seg, nseg
+    scene["init_state"][2] = psi0
+    env = make_oracle(cfg, scene)
+    cenv = c_oracle.COracleEnv(cfg, params.ray_table(cfg["n_rays"]))
+    cenv.set_scene(scene["circles"], scene["poly_pose"], scene["poly_verts"], scene["poly_nv"], scene["poly_heading"])
+    cenv.set_path(seg, nseg)
+    env.reset(scene["init_state"])
+    cenv.reset(scene["init_state"])
+    rng = np.random.default_rng(1)
+    seen = np.zeros(V, dtype=np.int64)
+    prev_along = env.along.copy()
+    for k in range(120):
+        # steer towards the look-ahead point: the vessels follow their paths round the corners
+        act = np.stack([np.full(V, 1.0), np.clip(2.0 * env.navigation[:, 0, 3].astype(np.float64), -1, 1)])
+        env.step(act)
+        cenv.step(act)
+        for name in ("state", "navigation", "along", "reward", "reached_goal", "done", "path_seg", "ranges"):
+            assert same_bits(getattr(cenv, name), np.asarray(getattr(env, name)).reshape(getattr(cenv, name).shape)), (name, k)
+        assert (env.path_seg >= seen).all() and (env.path_seg < nseg).all()     # never back, never past the last
+        seen = env.path_seg.copy()
+    assert (seen > 0).mean() > 0.5                                              # most vessels turned a corner
+    assert env.reached_goal.any()
+    total = (seg[:, :, 5] * (np.arange(seg.shape[1])[None, :] < nseg[:, None])).sum(axis=1)
+    assert np.all(env.along[env.reached_goal.astype(bool)] >= total[env.reached_goal.astype(bool)] - cfg["goal_radius"] - 1e-9)
+
+
+def test_one_segment_polyline_is_the_straight_path():
+    from tests.helpers import make_oracle
+
+    V = 40
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=V)
+    a = make_oracle(cfg, scene)
+    poly = dict(scene, path=scene["path"][:, None, :].copy(), path_nseg=np.ones(V, dtype=np.int32))
+    b = make_oracle(cfg, poly)
+    a.reset(scene["init_state"])
+    b.reset(scene["init_state"])
+    acts = scenarios.random_actions(V, 6, seed=2)
+    for k in range(6):
+        a.step(acts[k])
+        b.step(acts[k])
+        for name in ("navigation", "along", "reward", "reached_goal"):
+            assert same_bits(getattr(a, name), getattr(b, name)), name

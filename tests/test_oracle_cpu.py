@@ -215,6 +215,8 @@ def test_oracles_reproduce_the_committed_regression_vectors():
             assert same_bits(e.ranges, g[f"ranges_{k}"]) and same_bits(e.hit, g[f"hit_{k}"])
             assert same_bits(e.state, g[f"state_{k}"])
         for name, attr in PAIRS.items():
+            if f"final_{name}" not in g.files:
+                continue      # a buffer younger than the committed vectors
             want = g[f"final_{name}"]
             assert same_bits(np.asarray(getattr(e, attr)).reshape(want.shape), want), name
     # the same rollout with the closest-point-of-approach index
