@@ -246,6 +246,18 @@ __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P,
 enum ObstRec { OB_MX = 0, OB_MY, OB_RVX, OB_RVY, OB_DIST, OB_COUNT = 5 };  // per obstacle
 enum PolyRec { PB_X = 0, PB_Y, PB_HEADING, PB_COUNT = 3 };                  // per polygon
 
+// Running (inclusive) sum over the 64 lanes of a wave, every lane active:
+// shifts within rows of 16 lanes, then the two row broadcasts.
+__device__ __forceinline__ int wave_inclusive_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 __device__ __forceinline__ int2 pack_meta(int first, int cnt, int el, int oid) {
     return make_int2(first | (cnt << 16), el | (oid << 8));
 }
@@ -441,6 +453,32 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     const int tid = threadIdx.x;
     const int nthr = FIXED ? DefaultShape::NTHR : (int)blockDim.x;
     const int lane = tid & 63;
+    // The calling wave (all 64 lanes) appends lane L's `cnt` records (prim, 0..cnt-1)
+    // to one end of the pair list: the lanes share the slots evenly, each finding
+    // the lane its slot belongs to by bisection over the running counts, so the
+    // time goes with the wave's total and not with its widest primitive.
+    auto wave_append = [&](int cnt, unsigned int prim, int* counter, bool downward) {
+        const int incl = wave_inclusive_sum(cnt);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total == 0) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(counter, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int excl = incl - cnt;
+        for (int j0 = 0; j0 < total; j0 += 64) {
+            const int j = j0 + lane;
+            int lo4 = 0;  // 4 x the number of lanes whose records all lie before slot j
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int probe = __builtin_amdgcn_ds_bpermute(lo4 + (step - 1) * 4, incl);
+                lo4 = probe <= j ? lo4 + step * 4 : lo4;
+            }
+            const int k = j - __builtin_amdgcn_ds_bpermute(lo4, excl);
+            const unsigned int pp = (unsigned int)__builtin_amdgcn_ds_bpermute(lo4, (int)prim);
+            const int slot = base + j;  // writes stay inside the list even when it overflows
+            if (j < total && slot < cap) pair_put(downward ? cap - 1 - slot : slot, pp, (unsigned int)k);
+        }
+    };
     const double range = a.sensor_range;
     const float frange = (float)range * kRangeSlack;
     const float inv_delta = (float)R * (1.0f / 6.2831853f);
@@ -476,172 +514,168 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
 
     // ---- phase 1: primitives.  Circles go to the highest thread ids, so that
     // on small tiles they do not share a wave with the first edges.
-    for (int i = nthr - 1 - tid; i < n_circ; i += nthr) {
-        const int el = fast_div(i, inv_C);
-        const int j = i - el * C;
-        const int e = e0 + el;
-        double* c = a.circles + ((size_t)e0 * C + i) * 5;
-        double cx = c[0], cy = c[1];
-        const double rad = c[2], vx = c[3], vy = c[4];
-        const double* er = a.envrec + (size_t)e * ER_COUNT;
-        if (a.is_step && er[ER_RESET] == 0.0) {  // a restarted env's obstacles were just put back by k_vessel
-            cx = cx + vx * a.dt;
-            cy = cy + vy * a.dt;
-            c[0] = cx;
-            c[1] = cy;
-        }
-        const double psi = a.state[2 * (size_t)V + e];
-        const double mx = cx - a.state[e];
-        const double my = cy - a.state[(size_t)V + e];
-        const double mm = mx * mx + my * my;
-        const double cc = mm - rad * rad;
-        const bool on = rad > 0.0;
-        circ[i * 3 + 0] = on ? mx : 0.0;
-        circ[i * 3 + 1] = on ? my : 0.0;
-        circ[i * 3 + 2] = on ? cc : __builtin_inf();
-        // obstacle record for phase 2
-        double* ob = obst + (el * O + j);
-        ob[OB_MX * ob_n] = mx;
-        ob[OB_MY * ob_n] = my;
-        ob[OB_RVX * ob_n] = vx - er[ER_VOX];
-        ob[OB_RVY * ob_n] = vy - er[ER_VOY];
-        ob[OB_DIST * ob_n] = on ? (__builtin_sqrt(mm) - rad) - a.vessel_radius : __builtin_inf();
-        // candidate rays
-        const float fr = (float)rad, fmx = (float)mx, fmy = (float)my;
-        const float fmm = fmx * fmx + fmy * fmy;
+    const int wave0 = __builtin_amdgcn_readfirstlane(tid & ~63);  // first thread of this wave
+    for (int ib = 0; ib < n_circ; ib += nthr) {
+        if (ib + nthr - 64 - wave0 >= n_circ) continue;  // nothing for this wave
+        const int i = ib + nthr - 1 - tid;
         int2 iv = make_int2(0, 0);
-        if (!on) {
-            // absent slot
-        } else if (!(fmm > fr * fr * 1.001f)) {
-            iv.y = R;  // vessel inside or touching: every ray can hit
-        } else if (fast_sqrtf(fmm) - fr > frange) {
-            // wholly beyond sensor range
-        } else {
-            const float xc = scan_index(fast_atan2f(fmy, fmx), (float)psi, inv_delta);
-            const float hw = fast_atan2f(fr, fast_sqrtf(fmm - fr * fr)) * inv_delta;
-            iv = make_interval(xc - hw, xc + hw, R, margin);
-        }
-        AUV_CHECK(i >= 0 && i < TE * C && el >= 0 && el < ne && j >= 0 && j < C && iv.x >= 0 && iv.x < R && iv.y <= R);
-        meta[i] = pack_meta(iv.x, iv.y, el, j);
-        if (iv.y > 0) {
-            const int base = atomicAdd(&wsum[kCntCircle], iv.y);
-            const int room = min(iv.y, cap - base);  // writes stay inside the list even when it overflows
-            AUV_CHECK(base >= 0 && (room <= 0 || base + room <= cap));
-            for (int k = 0; k < room; ++k) pair_put(base + k, (unsigned int)i, (unsigned int)k);
-        }
-    }
-    for (int i = tid; i < ne * S; i += nthr) {
-        const int el = fast_div(i, inv_S);
-        const int s = i - el * S;
-        const int q = fast_div(s, inv_NV);
-        const int k = s - q * NV;
-        const int e = e0 + el;
-        const size_t ep = (size_t)e * P + q;
-        const int nv = a.poly_nv[ep];
-        const double reach2 = a.poly_reach2[ep];
-        const double* p = a.poly_pose + ep * 6;
-        // every vertex slot exists in memory, so the loads need not wait for nv
-        const double* vb = a.poly_rot + ep * NV * 2;  // already turned to the ship's heading
-        const int k1c = (k + 1 < NV) ? k + 1 : 0;
-        const double vkx = vb[2 * k], vky = vb[2 * k + 1];
-        const double v1x = vb[2 * k1c], v1y = vb[2 * k1c + 1], v0x = vb[0], v0y = vb[1];
-        double X = p[0], Y = p[1];
-        const double pvx = p[4], pvy = p[5];
-        if (a.is_step && a.envrec[(size_t)e * ER_COUNT + ER_RESET] == 0.0) {
-            X = X + pvx * a.dt;
-            Y = Y + pvy * a.dt;
-        }
-        const double px = a.state[e], py = a.state[(size_t)V + e];
-        const double psi = a.state[2 * (size_t)V + e];
-        if (k == 0) {
-            // one edge thread per polygon files its obstacle record for phase 2
+        if (i < n_circ) {
+            const int el = fast_div(i, inv_C);
+            const int j = i - el * C;
+            const int e = e0 + el;
+            double* c = a.circles + ((size_t)e0 * C + i) * 5;
+            double cx = c[0], cy = c[1];
+            const double rad = c[2], vx = c[3], vy = c[4];
             const double* er = a.envrec + (size_t)e * ER_COUNT;
-            double* ob = obst + (el * O + C + q);
-            ob[OB_MX * ob_n] = X - px;
-            ob[OB_MY * ob_n] = Y - py;
-            ob[OB_RVX * ob_n] = pvx - er[ER_VOX];
-            ob[OB_RVY * ob_n] = pvy - er[ER_VOY];
-            double* pb = pobs + (el * P + q);
-            pb[PB_X * pb_n] = X;  // advanced position, written back in phase 2
-            pb[PB_Y * pb_n] = Y;
-            // the heading column of the CPA index, or (RISK == 1) the ship's beam for the reference's distance
-            pb[PB_HEADING * pb_n] = RISK == 1 ? a.poly_beam[ep] : a.poly_heading[ep];
-        }
-        double ax = 0.0, ay = 0.0, ex = 0.0, ey = 0.0, nt = 0.0, dd = __builtin_inf();
-        int cross = 0;
-        int2 iv = make_int2(0, 0);
-        if (k < nv) {
-            const bool wrap = k + 1 >= nv;  // the last edge closes on vertex 0
-            const double bx = wrap ? v0x : v1x, by_ = wrap ? v0y : v1y;
-            const double Ax = X + vkx;
-            const double Ay = Y + vky;
-            const double Bx = X + bx;
-            const double By = Y + by_;
-            ax = Ax - px;
-            ay = Ay - py;
-            const double by = By - py;
-            ex = Bx - Ax;
-            ey = By - Ay;
-            nt = ax * ey - ay * ex;
-            // point-to-edge distance and crossing-number bit (vessel at the origin)
-            const double ee = ex * ex + ey * ey;
-            double tp = 0.0;
-            if (ee > 0.0) {
-                tp = (0.0 - (ax * ex + ay * ey)) / ee;
-                tp = tp < 0.0 ? 0.0 : tp;
-                tp = tp > 1.0 ? 1.0 : tp;
+            if (a.is_step && er[ER_RESET] == 0.0) {  // a restarted env's obstacles were just put back by k_vessel
+                cx = cx + vx * a.dt;
+                cy = cy + vy * a.dt;
+                c[0] = cx;
+                c[1] = cy;
             }
-            const double qx = ax + tp * ex;
-            const double qy = ay + tp * ey;
-            dd = qx * qx + qy * qy;  // squared: the one square root per polygon is taken in phase 2
-            const bool up = (ay <= 0.0) && (by > 0.0) && (nt > 0.0);
-            const bool dn = (by <= 0.0) && (ay > 0.0) && (nt < 0.0);
-            cross = (up || dn) ? 1 : 0;
-            // candidate rays: the arc between the bearings of the two endpoints
-            const float fax = (float)ax, fay = (float)ay, fex = (float)ex, fey = (float)ey;
-            const float fbx = fax + fex, fby = fay + fey;
-            const float dmin = fast_sqrtf((float)dd);
-            const float aa = fax * fax + fay * fay, bb = fbx * fbx + fby * fby;
-            // an edge of a convex polygon that faces away from a vessel outside it is no LiDAR surface (polygon_reach2)
-            const double cmx = X - px, cmy = Y - py;
-            const bool faces_away = reach2 >= 0.0 && (cmx * cmx + cmy * cmy) > reach2 && nt > 0.0;
-            if (dmin > frange || faces_away) {
-                // wholly beyond sensor range, or never a LiDAR surface: stays empty
-            } else if (aa < 1e-6f || bb < 1e-6f || dmin < 1e-3f) {
-                iv.y = R;  // an endpoint (or the edge) is on top of the vessel: bearings are meaningless
+            const double psi = a.state[2 * (size_t)V + e];
+            const double mx = cx - a.state[e];
+            const double my = cy - a.state[(size_t)V + e];
+            const double mm = mx * mx + my * my;
+            const double cc = mm - rad * rad;
+            const bool on = rad > 0.0;
+            circ[i * 3 + 0] = on ? mx : 0.0;
+            circ[i * 3 + 1] = on ? my : 0.0;
+            circ[i * 3 + 2] = on ? cc : __builtin_inf();
+            // obstacle record for phase 2
+            double* ob = obst + (el * O + j);
+            ob[OB_MX * ob_n] = mx;
+            ob[OB_MY * ob_n] = my;
+            ob[OB_RVX * ob_n] = vx - er[ER_VOX];
+            ob[OB_RVY * ob_n] = vy - er[ER_VOY];
+            ob[OB_DIST * ob_n] = on ? (__builtin_sqrt(mm) - rad) - a.vessel_radius : __builtin_inf();
+            // candidate rays
+            const float fr = (float)rad, fmx = (float)mx, fmy = (float)my;
+            const float fmm = fmx * fmx + fmy * fmy;
+            if (!on) {
+                // absent slot
+            } else if (!(fmm > fr * fr * 1.001f)) {
+                iv.y = R;  // vessel inside or touching: every ray can hit
+            } else if (fast_sqrtf(fmm) - fr > frange) {
+                // wholly beyond sensor range
             } else {
-                const float xa = scan_index(fast_atan2f(fay, fax), (float)psi, inv_delta);
-                const float xb = scan_index(fast_atan2f(fby, fbx), (float)psi, inv_delta);
-                float d = xb - xa;
-                d = d > half_scan ? d - (float)R : d;
-                d = d < -half_scan ? d + (float)R : d;
-                if (fabsf(d) > half_scan - 1.5f) {
-                    iv.y = R;  // subtends ~180 deg: the short way round is ambiguous
+                const float xc = scan_index(fast_atan2f(fmy, fmx), (float)psi, inv_delta);
+                const float hw = fast_atan2f(fr, fast_sqrtf(fmm - fr * fr)) * inv_delta;
+                iv = make_interval(xc - hw, xc + hw, R, margin);
+            }
+            AUV_CHECK(i >= 0 && i < TE * C && el >= 0 && el < ne && j >= 0 && j < C && iv.x >= 0 && iv.x < R && iv.y <= R);
+            meta[i] = pack_meta(iv.x, iv.y, el, j);
+        }
+        wave_append(iv.y, (unsigned int)i, &wsum[kCntCircle], false);
+    }
+    for (int ib = 0; ib < ne * S; ib += nthr) {
+        if (ib + wave0 >= ne * S) continue;  // nothing for this wave
+        const int i = ib + tid;
+        int2 iv = make_int2(0, 0);
+        if (i < ne * S) {
+            const int el = fast_div(i, inv_S);
+            const int s = i - el * S;
+            const int q = fast_div(s, inv_NV);
+            const int k = s - q * NV;
+            const int e = e0 + el;
+            const size_t ep = (size_t)e * P + q;
+            const int nv = a.poly_nv[ep];
+            const double reach2 = a.poly_reach2[ep];
+            const double* p = a.poly_pose + ep * 6;
+            // every vertex slot exists in memory, so the loads need not wait for nv
+            const double* vb = a.poly_rot + ep * NV * 2;  // already turned to the ship's heading
+            const int k1c = (k + 1 < NV) ? k + 1 : 0;
+            const double vkx = vb[2 * k], vky = vb[2 * k + 1];
+            const double v1x = vb[2 * k1c], v1y = vb[2 * k1c + 1], v0x = vb[0], v0y = vb[1];
+            double X = p[0], Y = p[1];
+            const double pvx = p[4], pvy = p[5];
+            if (a.is_step && a.envrec[(size_t)e * ER_COUNT + ER_RESET] == 0.0) {
+                X = X + pvx * a.dt;
+                Y = Y + pvy * a.dt;
+            }
+            const double px = a.state[e], py = a.state[(size_t)V + e];
+            const double psi = a.state[2 * (size_t)V + e];
+            if (k == 0) {
+                // one edge thread per polygon files its obstacle record for phase 2
+                const double* er = a.envrec + (size_t)e * ER_COUNT;
+                double* ob = obst + (el * O + C + q);
+                ob[OB_MX * ob_n] = X - px;
+                ob[OB_MY * ob_n] = Y - py;
+                ob[OB_RVX * ob_n] = pvx - er[ER_VOX];
+                ob[OB_RVY * ob_n] = pvy - er[ER_VOY];
+                double* pb = pobs + (el * P + q);
+                pb[PB_X * pb_n] = X;  // advanced position, written back in phase 2
+                pb[PB_Y * pb_n] = Y;
+                // the heading column of the CPA index, or (RISK == 1) the ship's beam for the reference's distance
+                pb[PB_HEADING * pb_n] = RISK == 1 ? a.poly_beam[ep] : a.poly_heading[ep];
+            }
+            double ax = 0.0, ay = 0.0, ex = 0.0, ey = 0.0, nt = 0.0, dd = __builtin_inf();
+            int cross = 0;
+            if (k < nv) {
+                const bool wrap = k + 1 >= nv;  // the last edge closes on vertex 0
+                const double bx = wrap ? v0x : v1x, by_ = wrap ? v0y : v1y;
+                const double Ax = X + vkx;
+                const double Ay = Y + vky;
+                const double Bx = X + bx;
+                const double By = Y + by_;
+                ax = Ax - px;
+                ay = Ay - py;
+                const double by = By - py;
+                ex = Bx - Ax;
+                ey = By - Ay;
+                nt = ax * ey - ay * ex;
+                // point-to-edge distance and crossing-number bit (vessel at the origin)
+                const double ee = ex * ex + ey * ey;
+                double tp = 0.0;
+                if (ee > 0.0) {
+                    tp = (0.0 - (ax * ex + ay * ey)) / ee;
+                    tp = tp < 0.0 ? 0.0 : tp;
+                    tp = tp > 1.0 ? 1.0 : tp;
+                }
+                const double qx = ax + tp * ex;
+                const double qy = ay + tp * ey;
+                dd = qx * qx + qy * qy;  // squared: the one square root per polygon is taken in phase 2
+                const bool up = (ay <= 0.0) && (by > 0.0) && (nt > 0.0);
+                const bool dn = (by <= 0.0) && (ay > 0.0) && (nt < 0.0);
+                cross = (up || dn) ? 1 : 0;
+                // candidate rays: the arc between the bearings of the two endpoints
+                const float fax = (float)ax, fay = (float)ay, fex = (float)ex, fey = (float)ey;
+                const float fbx = fax + fex, fby = fay + fey;
+                const float dmin = fast_sqrtf((float)dd);
+                const float aa = fax * fax + fay * fay, bb = fbx * fbx + fby * fby;
+                // an edge of a convex polygon that faces away from a vessel outside it is no LiDAR surface (polygon_reach2)
+                const double cmx = X - px, cmy = Y - py;
+                const bool faces_away = reach2 >= 0.0 && (cmx * cmx + cmy * cmy) > reach2 && nt > 0.0;
+                if (dmin > frange || faces_away) {
+                    // wholly beyond sensor range, or never a LiDAR surface: stays empty
+                } else if (aa < 1e-6f || bb < 1e-6f || dmin < 1e-3f) {
+                    iv.y = R;  // an endpoint (or the edge) is on top of the vessel: bearings are meaningless
                 } else {
-                    const float lo = d >= 0.0f ? xa : xa + d;
-                    iv = make_interval(lo, lo + fabsf(d), R, margin);
+                    const float xa = scan_index(fast_atan2f(fay, fax), (float)psi, inv_delta);
+                    const float xb = scan_index(fast_atan2f(fby, fbx), (float)psi, inv_delta);
+                    float d = xb - xa;
+                    d = d > half_scan ? d - (float)R : d;
+                    d = d < -half_scan ? d + (float)R : d;
+                    if (fabsf(d) > half_scan - 1.5f) {
+                        iv.y = R;  // subtends ~180 deg: the short way round is ambiguous
+                    } else {
+                        const float lo = d >= 0.0f ? xa : xa + d;
+                        iv = make_interval(lo, lo + fabsf(d), R, margin);
+                    }
                 }
             }
+            double* sg = seg + (size_t)i * (FIXED ? 4 : 5);
+            sg[0] = ax;
+            sg[1] = ay;
+            sg[2] = ex;
+            sg[3] = ey;
+            if (!FIXED) sg[4] = nt;
+            edist[i] = dd;
+            ecross_put(i, k == 0 ? (cross | (nv << 1)) : cross);  // edge 0 also carries the vertex count
+            AUV_CHECK(i >= 0 && i < TE * S && el >= 0 && el < ne && q >= 0 && q < P && iv.x >= 0 && iv.x < R && iv.y <= R);
+            meta[n_circ + i] = pack_meta(iv.x, iv.y, el, C + q);
         }
-        double* sg = seg + (size_t)i * (FIXED ? 4 : 5);
-        sg[0] = ax;
-        sg[1] = ay;
-        sg[2] = ex;
-        sg[3] = ey;
-        if (!FIXED) sg[4] = nt;
-        edist[i] = dd;
-        ecross_put(i, k == 0 ? (cross | (nv << 1)) : cross);  // edge 0 also carries the vertex count
-        AUV_CHECK(i >= 0 && i < TE * S && el >= 0 && el < ne && q >= 0 && q < P && iv.x >= 0 && iv.x < R && iv.y <= R);
-        meta[n_circ + i] = pack_meta(iv.x, iv.y, el, C + q);
-        if (iv.y > 0) {
-            const int used = atomicAdd(&wsum[kCntEdge], iv.y);
-            const int top = cap - used;  // exclusive upper slot of this primitive's run
-            const int room = min(iv.y, top);
-            AUV_CHECK(top <= cap && (room <= 0 || top - room >= 0));
-#pragma nounroll  // a handful of rays per edge: the unrolled form only adds set-up
-            for (int kk = 0; kk < room; ++kk)
-                pair_put(top - 1 - kk, (unsigned int)(n_circ + i), (unsigned int)kk);
-        }
+        wave_append(iv.y, (unsigned int)(n_circ + i), &wsum[kCntEdge], true);
     }
     if (tid < ne) {
         env[tid * 2] = env_c;
