@@ -835,15 +835,18 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     // ---- phase 3: LiDAR sweeps (same barrier interval as phase 2: they share nothing)
     if (fits) {
         // the whole pair list is in LDS: the keys of sweep 0 stay in registers,
-        // sweep 1 does no arithmetic.  Pair w: circles first, then edges.
+        // sweep 1 does no arithmetic.  Pair w: circles first, then edges.  The
+        // waves that ran a task of phase 2 take no pairs when others are left: a
+        // task is longer than the rest's share of the sweep.
+        const int n_busy = a.with_meta ? 128 : 64;
+        const int sw0 = nthr > n_busy ? n_busy : 0;  // first sweeping thread
+        const int sw_n = nthr - sw0, sw_t = tid - sw0;
         PairHit kept[kKeep];
 #pragma unroll
         for (int j = 0; j < kKeep; ++j) {
             kept[j].ok = false;
-            // later rounds start half a workgroup on: the short end of the list falls to the wave that
-            // ran the long task of phase 2
-            const int w = (j == 0 ? tid : ((tid + (nthr >> 1)) & (nthr - 1))) + j * nthr;
-            if (w < total) {
+            const int w = sw_t + j * sw_n;
+            if (sw_t >= 0 && w < total) {
                 AUV_CHECK((w < n_cp ? w : cap - n_ep + (w - n_cp)) >= 0 && (w < n_cp ? w : cap - n_ep + (w - n_cp)) < cap);
                 kept[j] = pair_test<FIXED>(pair_get(w < n_cp ? w : cap - n_ep + (w - n_cp)), R, n_circ, range, meta, env, circ,
                                     seg, a.ray_dirs);
@@ -851,7 +854,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                 if (kept[j].ok) atomicMin(&best[kept[j].slot], kept[j].key);
             }
         }
-        for (int w = tid + kKeep * nthr; w < total; w += nthr) {
+        for (int w = sw_t + kKeep * sw_n; sw_t >= 0 && w < total; w += sw_n) {
             const PairHit h = pair_test<FIXED>(pair_get(w < n_cp ? w : cap - n_ep + (w - n_cp)), R, n_circ, range, meta, env,
                                         circ, seg, a.ray_dirs);
             if (h.ok) atomicMin(&best[h.slot], h.key);
@@ -862,7 +865,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
 #pragma unroll
         for (int j = 0; j < kKeep; ++j)
             if (kept[j].ok && best[kept[j].slot] == kept[j].key) atomicMin(&ids[kept[j].slot], kept[j].oid);
-        for (int w = tid + kKeep * nthr; w < total; w += nthr) {
+        for (int w = sw_t + kKeep * sw_n; sw_t >= 0 && w < total; w += sw_n) {
             const PairHit h = pair_test<FIXED>(pair_get(w < n_cp ? w : cap - n_ep + (w - n_cp)), R, n_circ, range, meta, env,
                                         circ, seg, a.ray_dirs);
             if (h.ok && best[h.slot] == h.key) atomicMin(&ids[h.slot], h.oid);
