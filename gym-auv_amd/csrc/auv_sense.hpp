@@ -153,9 +153,8 @@ __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
 struct SenseArgs {
     Dims d;
     int TE;       // envs per workgroup
-    int lds[12];  // byte offsets of the LDS arrays (sense_layout, computed once on the host): env, circ, seg,
-                  // best, obst, edist, meta, offs, ids, pairs, ecross, wsum
-    int cap;      // pair-list slots per round
+    int lds[10];  // byte offsets of the LDS arrays (sense_layout, computed once on the host): env, circ, seg,
+                  // best, obst, edist, ids, ecross, live, wsum
     int is_step;  // 1: advance obstacles, finish the reward; 0: after reset / plain sense
     int with_meta;  // 0: bearing, course and risk of the obstacles are not refreshed by this pass
     int refresh_heading;  // 0: the heading_ts column (a constant of the scene) is rewritten only for restarting envs
@@ -195,16 +194,14 @@ struct SenseArgs {
 };
 
 struct SenseLayout {
-    size_t env, circ, seg, best, obst, edist, meta, offs, ids, pairs, ecross, wsum, total;  // byte offsets
+    size_t env, circ, seg, best, obst, edist, ids, ecross, live, wsum, total;  // byte offsets
 };
 
-// LDS image per tile (f64 blocks first, 16-B aligned int4 block, then words).
-//   env[TE][2] cos psi, sin psi       circ[TE*C][3] mx,my,cc       seg[TE*S][5] ax,ay,ex,ey,nt
+// LDS image per tile (f64 blocks first, then words and bytes).
+//   env[TE][2] cos psi, sin psi, then [TE] psi      circ[TE*C][4] mx,my,cc,radius      seg[TE*S][5] ax,ay,ex,ey,nt
 //   best[TE*R] u64     obst: 5 fields [TE*O] mx,my,rvx,rvy,dist then 3 fields [TE*P] x,y,heading
 //                      (field-major: the lanes of a wave walk the banks)
-//   edist[TE*S] f64    meta[NP] int2 {first | cnt<<16, env | obstacle<<8}
-//   ids[TE*R]   pairs[cap]   ecross[TE*S]   wsum[24]
-//   offs[NP+1] (only the overflow path, after phase 2 is over) lies over obst.
+//   edist[TE*S] f64    ids[TE*R]   ecross[TE*S]   live[TE*S] numbers of the edges that have candidate rays   wsum[8]
 // With a network evaluated in-kernel (cnn_kind >= 0) its weights and two
 // activation buffers per env reuse the bytes in front of best[], which are
 // dead by then; the front is padded when it is smaller than that.
@@ -212,33 +209,25 @@ __host__ __device__ inline size_t sense_cnn_bytes(int TE, int cnn_kind) {
     return cnn_kind < 0 ? 0 : ((size_t)((cnn_n_weights(cnn_kind) + 3) & ~3) + (size_t)TE * cnn_act_floats(cnn_kind)) * 4;
 }
 // packed: the narrow image of the compile-time shape (DefaultShape): edges without their stored cross
-// product, 16-bit pairs, 8-bit crossing records; 3.8 KB smaller, which is a seventh workgroup per CU.
-__host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P, int NV, int cap, int cnn_kind,
-                                                    bool packed = false) {
+// product, 8-bit crossing records and edge numbers.
+__host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P, int NV, int cnn_kind, bool packed = false) {
     SenseLayout L;
     const size_t S = (size_t)P * NV, O = (size_t)C + P;
-    const size_t NP = (size_t)TE * ((size_t)C + S);
     size_t o = 0;
-    L.env = o; o += (size_t)TE * 2 * 8;
-    L.circ = o; o += (size_t)TE * C * 3 * 8;
+    L.env = o; o += (size_t)TE * 3 * 8;
+    L.circ = o; o += (size_t)TE * C * 4 * 8;
     L.seg = o; o += (size_t)TE * S * (packed ? 4 : 5) * 8;
     const size_t act = sense_cnn_bytes(TE, cnn_kind);
     o = o < act ? act : o;
+    o = (o + 7) & ~(size_t)7;
     L.best = o; o += (size_t)TE * R * 8;
-    {
-        const size_t ob = ((size_t)TE * O * 5 + (size_t)TE * P * 3) * 8, of = (NP + 1) * 4;
-        L.obst = o;
-        L.offs = o;
-        o += ob > of ? ob : of;
-    }
+    L.obst = o; o += ((size_t)TE * O * 5 + (size_t)TE * P * 3) * 8;
     L.edist = o; o += (size_t)TE * S * 8;
-    o = (o + 15) & ~(size_t)15;
-    L.meta = o; o += NP * 8;
     L.ids = o; o += (size_t)TE * R * 4;
-    L.pairs = o; o += (size_t)cap * (packed ? 2 : 4);
     L.ecross = o; o += (size_t)TE * S * (packed ? 1 : 4);
+    L.live = o; o += (size_t)TE * S * (packed ? 1 : 2);
     o = (o + 3) & ~(size_t)3;
-    L.wsum = o; o += 24 * 4;
+    L.wsum = o; o += 8 * 4;
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
@@ -258,13 +247,9 @@ __device__ __forceinline__ int wave_inclusive_sum(int v) {
     return v;
 }
 
-__device__ __forceinline__ int2 pack_meta(int first, int cnt, int el, int oid) {
-    return make_int2(first | (cnt << 16), el | (oid << 8));
-}
-__device__ __forceinline__ int meta_count(int2 m) { return (int)((unsigned)m.x >> 16); }
-
-// One (primitive, ray) pair of the dense list: decode, build the ray, run the
-// exact test.  `slot` = accumulator index of the ray, `oid` = obstacle id.
+// One (primitive, ray) pair: build the ray, run the exact test.  p = primitive
+// (circles first), el = env of the tile, r = ray, oid = obstacle id; `slot` =
+// accumulator index of the ray.
 struct PairHit {
     bool ok;
     int slot;
@@ -272,15 +257,31 @@ struct PairHit {
     unsigned long long key;
 };
 
+// A hit remembered between the two sweeps: three registers when ray slot (< 2^28) and obstacle id (< 16) share a
+// word, as they do in the compile-time shape, else four.
 template <bool PACKED>
-__device__ __forceinline__ PairHit pair_test(unsigned int pr, int R, int n_circ, double range, const int2* meta,
+struct KeptHit {
+    unsigned long long key;
+    unsigned int a, b;  // PACKED: a = slot << 4 | oid, ~0 for none;  else a = slot, ~0 for none, b = oid
+    __device__ __forceinline__ void clear() { a = 0xffffffffu; }
+    __device__ __forceinline__ void set(const PairHit& h) {
+        key = h.key;
+        if (PACKED) {
+            a = h.ok ? ((unsigned int)h.slot << 4) | h.oid : 0xffffffffu;
+        } else {
+            a = h.ok ? (unsigned int)h.slot : 0xffffffffu;
+            b = h.oid;
+        }
+    }
+    __device__ __forceinline__ bool ok() const { return a != 0xffffffffu; }
+    __device__ __forceinline__ int slot() const { return (int)(PACKED ? a >> 4 : a); }
+    __device__ __forceinline__ unsigned int oid() const { return PACKED ? a & 15u : b; }
+};
+
+template <bool PACKED>
+__device__ __forceinline__ PairHit pair_test(int p, int el, int r, unsigned int oid, int R, int n_circ, double range,
                                              const double* env, const double* circ, const double* seg,
                                              const double* ray_dirs) {
-    const int p = (int)(pr >> 16);
-    const int2 m = meta[p];
-    const int el = m.y & 0xff;
-    int r = (m.x & 0xffff) + (int)(pr & 0xffffu);
-    r = r >= R ? r - R : r;
     const double cpsi = env[el * 2], spsi = env[el * 2 + 1];
     const double cb = ray_dirs[2 * r], sb = ray_dirs[2 * r + 1];
     const double dx = cpsi * cb - spsi * sb;
@@ -288,7 +289,7 @@ __device__ __forceinline__ PairHit pair_test(unsigned int pr, int R, int n_circ,
     double t = 0.0;
     bool ok;
     if (p < n_circ) {
-        ok = circle_hit(circ[3 * p], circ[3 * p + 1], circ[3 * p + 2], dx, dy, t);
+        ok = circle_hit(circ[4 * p], circ[4 * p + 1], circ[4 * p + 2], dx, dy, t);
     } else {
         const double* sg = seg + (size_t)(p - n_circ) * (PACKED ? 4 : 5);
         // packed edges recompute a x e, with the operations phase 1 files it with
@@ -297,7 +298,7 @@ __device__ __forceinline__ PairHit pair_test(unsigned int pr, int R, int n_circ,
     PairHit h;
     h.ok = ok && t < range;
     h.slot = el * R + r;
-    h.oid = (unsigned int)m.y >> 8;
+    h.oid = oid;
     h.key = t_key(t);
     return h;
 }
@@ -367,8 +368,7 @@ __device__ unsigned long long g_violations = 0ull;
 #define AUV_CHECK(cond)
 #endif
 
-constexpr int kCntCircle = 16, kCntEdge = 17;  // slots of wsum[] that count the circle and the edge pairs
-constexpr int kKeep = 4;  // pair-list passes whose hit keys stay in registers between the two sweeps
+constexpr int kCntLive = 0;  // slot of wsum[] that counts the edges that have candidate rays
 
 // The scene shape of the reference's default scenario at the benchmark's size:
 // 180 rays (utils/dataloader.py:13), 8 circles + 8 five-vertex ships per env,
@@ -376,11 +376,11 @@ constexpr int kKeep = 4;  // pair-list passes whose hit keys stay in registers b
 // compile-time constants (index arithmetic folds, loops over vertices unroll,
 // a dozen scalar registers are freed); every other shape takes the generic one.
 struct DefaultShape {
-    static constexpr int R = 180, C = 8, P = 8, NV = 5, TE = 4, NTHR = 256, CAP = 1024;
+    static constexpr int R = 180, C = 8, P = 8, NV = 5, TE = 4, NTHR = 256;
 };
-inline bool is_default_shape(const Dims& d, int te, int block, int cap) {
+inline bool is_default_shape(const Dims& d, int te, int block) {
     return d.R == DefaultShape::R && d.C == DefaultShape::C && d.P == DefaultShape::P && d.NV == DefaultShape::NV &&
-           te == DefaultShape::TE && block == DefaultShape::NTHR && cap == DefaultShape::CAP;
+           te == DefaultShape::TE && block == DefaultShape::NTHR;
 }
 
 // RISK: 0 = default risk index, 1 = the reference's index (auv_risk.hpp)
@@ -405,14 +405,13 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     const int NV = FIXED ? DefaultShape::NV : a.d.NV, O = FIXED ? DefaultShape::C + DefaultShape::P : a.d.O;
     const int S = P * NV;
     const int TE = FIXED ? DefaultShape::TE : a.TE;
-    const int cap = FIXED ? DefaultShape::CAP : a.cap;
-    struct { int env, circ, seg, best, obst, edist, meta, offs, ids, pairs, ecross, wsum; } L = {
-        a.lds[0], a.lds[1], a.lds[2], a.lds[3], a.lds[4], a.lds[5], a.lds[6], a.lds[7], a.lds[8], a.lds[9], a.lds[10], a.lds[11]};
+    struct { int env, circ, seg, best, obst, edist, ids, ecross, live, wsum; } L = {
+        a.lds[0], a.lds[1], a.lds[2], a.lds[3], a.lds[4], a.lds[5], a.lds[6], a.lds[7], a.lds[8], a.lds[9]};
     if (FIXED) {
         // constants but for the room an attached network takes in front of best[]
-        const SenseLayout T = sense_layout(TE, R, C, P, NV, cap, a.cnn_w ? a.cnn_kind : -1, true);
-        L = {(int)T.env, (int)T.circ, (int)T.seg, (int)T.best, (int)T.obst, (int)T.edist, (int)T.meta, (int)T.offs,
-             (int)T.ids, (int)T.pairs, (int)T.ecross, (int)T.wsum};
+        const SenseLayout T = sense_layout(TE, R, C, P, NV, a.cnn_w ? a.cnn_kind : -1, true);
+        L = {(int)T.env, (int)T.circ, (int)T.seg, (int)T.best, (int)T.obst, (int)T.edist, (int)T.ids, (int)T.ecross,
+             (int)T.live, (int)T.wsum};
     }
     double* env = reinterpret_cast<double*>(lds_raw + L.env);
     double* circ = reinterpret_cast<double*>(lds_raw + L.circ);
@@ -423,21 +422,9 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     double* pobs = obst + (size_t)OB_COUNT * ob_n;  // polygon-only fields
     const int pb_n = TE * P;
     double* edist = reinterpret_cast<double*>(lds_raw + L.edist);
-    int2* meta = reinterpret_cast<int2*>(lds_raw + L.meta);
-    int* offs = reinterpret_cast<int*>(lds_raw + L.offs);
     unsigned int* ids = reinterpret_cast<unsigned int*>(lds_raw + L.ids);
-    unsigned int* pairs = reinterpret_cast<unsigned int*>(lds_raw + L.pairs);
     int* ecross = reinterpret_cast<int*>(lds_raw + L.ecross);
-    // pair (primitive, ray offset) and crossing records: 16 + 16 bits and a word each, or 8 + 8 bits and a byte
-    auto pair_put = [&](int idx, unsigned int prim, unsigned int k) {
-        if (FIXED) reinterpret_cast<unsigned short*>(pairs)[idx] = (unsigned short)((prim << 8) | k);
-        else pairs[idx] = (prim << 16) | k;
-    };
-    auto pair_get = [&](int idx) -> unsigned int {
-        if (!FIXED) return pairs[idx];
-        const unsigned int v = reinterpret_cast<const unsigned short*>(pairs)[idx];
-        return ((v >> 8) << 16) | (v & 0xffu);
-    };
+    // crossing records and edge numbers: a word and a half-word each, or (compile-time shape) a byte
     auto ecross_put = [&](int idx, int v) {
         if (FIXED) reinterpret_cast<unsigned char*>(ecross)[idx] = (unsigned char)v;
         else ecross[idx] = v;
@@ -445,40 +432,23 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     auto ecross_get = [&](int idx) -> int {
         return FIXED ? (int)reinterpret_cast<const unsigned char*>(ecross)[idx] : ecross[idx];
     };
-    int* wsum = reinterpret_cast<int*>(lds_raw + L.wsum);  // [0..15] wave sums of the fallback scan, then the two pair counters
+    // numbers of the edges that have candidate rays, in the order their waves found them
+    auto live_put = [&](int idx, int edge) {
+        if (FIXED) (lds_raw + L.live)[idx] = (unsigned char)edge;
+        else reinterpret_cast<unsigned short*>(lds_raw + L.live)[idx] = (unsigned short)edge;
+    };
+    auto live_get = [&](int idx) -> int {
+        return FIXED ? (int)(lds_raw + L.live)[idx] : (int)reinterpret_cast<const unsigned short*>(lds_raw + L.live)[idx];
+    };
+    int* wsum = reinterpret_cast<int*>(lds_raw + L.wsum);
     const int e0 = blockIdx.x * TE;
     const int ne = min(TE, V - e0);
     const int n_circ = ne * C;
-    const int NP = n_circ + ne * S;
     const int tid = threadIdx.x;
     const int nthr = FIXED ? DefaultShape::NTHR : (int)blockDim.x;
     const int lane = tid & 63;
-    // The calling wave (all 64 lanes) appends lane L's `cnt` records (prim, 0..cnt-1)
-    // to one end of the pair list: the lanes share the slots evenly, each finding
-    // the lane its slot belongs to by bisection over the running counts, so the
-    // time goes with the wave's total and not with its widest primitive.
-    auto wave_append = [&](int cnt, unsigned int prim, int* counter, bool downward) {
-        const int incl = wave_inclusive_sum(cnt);
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        if (total == 0) return;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(counter, total);
-        base = __builtin_amdgcn_readfirstlane(base);
-        const int excl = incl - cnt;
-        for (int j0 = 0; j0 < total; j0 += 64) {
-            const int j = j0 + lane;
-            int lo4 = 0;  // 4 x the number of lanes whose records all lie before slot j
-#pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) {
-                const int probe = __builtin_amdgcn_ds_bpermute(lo4 + (step - 1) * 4, incl);
-                lo4 = probe <= j ? lo4 + step * 4 : lo4;
-            }
-            const int k = j - __builtin_amdgcn_ds_bpermute(lo4, excl);
-            const unsigned int pp = (unsigned int)__builtin_amdgcn_ds_bpermute(lo4, (int)prim);
-            const int slot = base + j;  // writes stay inside the list even when it overflows
-            if (j < total && slot < cap) pair_put(downward ? cap - 1 - slot : slot, pp, (unsigned int)k);
-        }
-    };
+    const int n_waves = nthr >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const double range = a.sensor_range;
     const float frange = (float)range * kRangeSlack;
     const float inv_delta = (float)R * (1.0f / 6.2831853f);
@@ -489,20 +459,16 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     const float inv_NV = __builtin_amdgcn_rcpf((float)NV), inv_O = __builtin_amdgcn_rcpf((float)(O > 0 ? O : 1));
 
     AUV_STAMP(0);
-    // ---- phase 0: accumulators.  The pair list is filled from both ends:
-    // circle pairs grow up from slot 0 (count in wsum[kCntCircle]), edge pairs grow down
-    // from slot cap (count in wsum[kCntEdge]), so a wave of the sweep sees one kind.
-    if (tid == 0) {
-        wsum[kCntCircle] = 0;
-        wsum[kCntEdge] = 0;
-    }
-    // heading sin/cos of the tile's vessels: requested now, filed at the end of
-    // phase 1, so that the first barrier does not wait for global memory
-    double env_c = 0.0, env_s = 0.0;
+    // ---- phase 0: accumulators
+    if (tid == 0) wsum[kCntLive] = 0;
+    // heading (and its sin/cos) of the tile's vessels: requested now, filed at the
+    // end of phase 1, so that the first barrier does not wait for global memory
+    double env_c = 0.0, env_s = 0.0, env_psi = 0.0;
     if (tid < ne) {  // ne <= 64 <= nthr
         const double* er = a.envrec + (size_t)(e0 + tid) * ER_COUNT;
         env_c = er[ER_COS];
         env_s = er[ER_SIN];
+        env_psi = a.state[2 * (size_t)V + e0 + tid];
     }
     const unsigned long long range_bits = (unsigned long long)__double_as_longlong(range);
     for (int f = tid; f < ne * R; f += nthr) {
@@ -512,13 +478,13 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     __syncthreads();
     AUV_STAMP(1);
 
-    // ---- phase 1: primitives.  Circles go to the highest thread ids, so that
-    // on small tiles they do not share a wave with the first edges.
-    const int wave0 = __builtin_amdgcn_readfirstlane(tid & ~63);  // first thread of this wave
+    // ---- phase 1: geometry of the primitives.  Circles go to the highest
+    // thread ids, so that on small tiles they do not share a wave with the
+    // first edges.
+    const int wave0 = wave << 6;  // first thread of this wave
     for (int ib = 0; ib < n_circ; ib += nthr) {
         if (ib + nthr - 64 - wave0 >= n_circ) continue;  // nothing for this wave
         const int i = ib + nthr - 1 - tid;
-        int2 iv = make_int2(0, 0);
         if (i < n_circ) {
             const int el = fast_div(i, inv_C);
             const int j = i - el * C;
@@ -533,15 +499,15 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                 c[0] = cx;
                 c[1] = cy;
             }
-            const double psi = a.state[2 * (size_t)V + e];
             const double mx = cx - a.state[e];
             const double my = cy - a.state[(size_t)V + e];
             const double mm = mx * mx + my * my;
             const double cc = mm - rad * rad;
             const bool on = rad > 0.0;
-            circ[i * 3 + 0] = on ? mx : 0.0;
-            circ[i * 3 + 1] = on ? my : 0.0;
-            circ[i * 3 + 2] = on ? cc : __builtin_inf();
+            circ[i * 4 + 0] = on ? mx : 0.0;
+            circ[i * 4 + 1] = on ? my : 0.0;
+            circ[i * 4 + 2] = on ? cc : __builtin_inf();
+            circ[i * 4 + 3] = on ? rad : 0.0;
             // obstacle record for phase 2
             double* ob = obst + (el * O + j);
             ob[OB_MX * ob_n] = mx;
@@ -549,29 +515,17 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
             ob[OB_RVX * ob_n] = vx - er[ER_VOX];
             ob[OB_RVY * ob_n] = vy - er[ER_VOY];
             ob[OB_DIST * ob_n] = on ? (__builtin_sqrt(mm) - rad) - a.vessel_radius : __builtin_inf();
-            // candidate rays
-            const float fr = (float)rad, fmx = (float)mx, fmy = (float)my;
-            const float fmm = fmx * fmx + fmy * fmy;
-            if (!on) {
-                // absent slot
-            } else if (!(fmm > fr * fr * 1.001f)) {
-                iv.y = R;  // vessel inside or touching: every ray can hit
-            } else if (fast_sqrtf(fmm) - fr > frange) {
-                // wholly beyond sensor range
-            } else {
-                const float xc = scan_index(fast_atan2f(fmy, fmx), (float)psi, inv_delta);
-                const float hw = fast_atan2f(fr, fast_sqrtf(fmm - fr * fr)) * inv_delta;
-                iv = make_interval(xc - hw, xc + hw, R, margin);
-            }
-            AUV_CHECK(i >= 0 && i < TE * C && el >= 0 && el < ne && j >= 0 && j < C && iv.x >= 0 && iv.x < R && iv.y <= R);
-            meta[i] = pack_meta(iv.x, iv.y, el, j);
+            AUV_CHECK(i >= 0 && i < TE * C && el >= 0 && el < ne && j >= 0 && j < C);
         }
-        wave_append(iv.y, (unsigned int)i, &wsum[kCntCircle], false);
     }
+    // Edges: geometry, distance and crossing bit of every edge; the few that a
+    // ray can hit at all (in range, facing the vessel) are listed, and get their
+    // candidate rays after the barrier from one wave instead of occupying a lane
+    // in every wave here.
     for (int ib = 0; ib < ne * S; ib += nthr) {
         if (ib + wave0 >= ne * S) continue;  // nothing for this wave
         const int i = ib + tid;
-        int2 iv = make_int2(0, 0);
+        bool has_rays = false;
         if (i < ne * S) {
             const int el = fast_div(i, inv_S);
             const int s = i - el * S;
@@ -594,7 +548,6 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                 Y = Y + pvy * a.dt;
             }
             const double px = a.state[e], py = a.state[(size_t)V + e];
-            const double psi = a.state[2 * (size_t)V + e];
             if (k == 0) {
                 // one edge thread per polygon files its obstacle record for phase 2
                 const double* er = a.envrec + (size_t)e * ER_COUNT;
@@ -638,21 +591,103 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                 const bool up = (ay <= 0.0) && (by > 0.0) && (nt > 0.0);
                 const bool dn = (by <= 0.0) && (ay > 0.0) && (nt < 0.0);
                 cross = (up || dn) ? 1 : 0;
-                // candidate rays: the arc between the bearings of the two endpoints
-                const float fax = (float)ax, fay = (float)ay, fex = (float)ex, fey = (float)ey;
-                const float fbx = fax + fex, fby = fay + fey;
-                const float dmin = fast_sqrtf((float)dd);
-                const float aa = fax * fax + fay * fay, bb = fbx * fbx + fby * fby;
-                // an edge of a convex polygon that faces away from a vessel outside it is no LiDAR surface (polygon_reach2)
+                // an edge of a convex polygon that faces away from a vessel outside it is no LiDAR surface
+                // (polygon_reach2); nor is one wholly beyond sensor range
                 const double cmx = X - px, cmy = Y - py;
                 const bool faces_away = reach2 >= 0.0 && (cmx * cmx + cmy * cmy) > reach2 && nt > 0.0;
-                if (dmin > frange || faces_away) {
-                    // wholly beyond sensor range, or never a LiDAR surface: stays empty
-                } else if (aa < 1e-6f || bb < 1e-6f || dmin < 1e-3f) {
+                has_rays = !(fast_sqrtf((float)dd) > frange || faces_away);
+            }
+            double* sg = seg + (size_t)i * (FIXED ? 4 : 5);
+            sg[0] = ax;
+            sg[1] = ay;
+            sg[2] = ex;
+            sg[3] = ey;
+            if (!FIXED) sg[4] = nt;
+            edist[i] = dd;
+            ecross_put(i, k == 0 ? (cross | (nv << 1)) : cross);  // edge 0 also carries the vertex count
+            AUV_CHECK(i >= 0 && i < TE * S && el >= 0 && el < ne && q >= 0 && q < P);
+        }
+        const unsigned long long found = __ballot(has_rays);
+        if (found != 0ull) {  // same for the whole wave
+            int at = 0;
+            if (lane == 0) at = atomicAdd(&wsum[kCntLive], __popcll(found));
+            at = __builtin_amdgcn_readfirstlane(at) +
+                 (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(found >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)found, 0u));
+            AUV_CHECK(!has_rays || (at >= 0 && at < TE * S));
+            if (has_rays) live_put(at, i);
+        }
+    }
+    if (tid < ne) {
+        env[tid * 2] = env_c;
+        env[tid * 2 + 1] = env_s;
+        env[2 * TE + tid] = env_psi;
+    }
+    AUV_STAMP(2);
+    __syncthreads();
+    AUV_STAMP(3);
+
+    // ---- phase 2 and 3 share a barrier interval.  Phase 2, the obstacle-level
+    // outputs, is two tasks, each on a wave of its own; the other waves (all of
+    // them, when the workgroup has no more than that) run phase 3, the LiDAR
+    // sweep, in units of 64 primitives: the circles in thread order, then the
+    // listed edges.  A unit's wave gives each primitive its candidate rays
+    // [first, first + cnt), numbers the unit's (primitive, ray) pairs 0..total-1
+    // in lane order and shares them out evenly: pair j goes to lane j % 64, which
+    // finds the primitive by bisection over the running counts.  So the time goes
+    // with the number of pairs, not with the widest primitive.
+    const int n_tasks = a.with_meta ? 2 : 1;
+    const int first_ray_wave = n_waves > n_tasks ? n_tasks : 0;
+    const int n_ray_waves = n_waves - first_ray_wave;
+    const int n_live = wsum[kCntLive];
+    const int units_c = (n_circ + 63) >> 6, n_units = units_c + ((n_live + 63) >> 6);
+    struct Unit {
+        int incl, excl, total;      // running count of pairs up to and with this lane's primitive, without it; all
+        unsigned int desc, desc2;   // first ray, primitive, env and obstacle id of the lane's primitive
+    };
+    auto unit_open = [&](int u) -> Unit {
+        int2 iv = make_int2(0, 0);
+        int prim = 0, el = 0, oid = 0;
+        if (u < units_c) {
+            const int i = u * 64 + lane;
+            if (i < n_circ) {
+                el = fast_div(i, inv_C);
+                oid = i - el * C;
+                prim = i;
+                const double* c4 = circ + 4 * i;
+                const float fr = (float)c4[3], fmx = (float)c4[0], fmy = (float)c4[1];
+                const float fmm = fmx * fmx + fmy * fmy;
+                if (!(fr > 0.0f)) {
+                    // absent slot
+                } else if (!(fmm > fr * fr * 1.001f)) {
+                    iv.y = R;  // vessel inside or touching: every ray can hit
+                } else if (fast_sqrtf(fmm) - fr > frange) {
+                    // wholly beyond sensor range
+                } else {
+                    const float xc = scan_index(fast_atan2f(fmy, fmx), (float)env[2 * TE + el], inv_delta);
+                    const float hw = fast_atan2f(fr, fast_sqrtf(fmm - fr * fr)) * inv_delta;
+                    iv = make_interval(xc - hw, xc + hw, R, margin);
+                }
+            }
+        } else {
+            const int j = (u - units_c) * 64 + lane;
+            if (j < n_live) {
+                const int i = live_get(j);
+                AUV_CHECK(i >= 0 && i < ne * S);
+                el = fast_div(i, inv_S);
+                oid = C + fast_div(i - el * S, inv_NV);
+                prim = n_circ + i;
+                const double* sg = seg + (size_t)i * (FIXED ? 4 : 5);
+                // candidate rays: the arc between the bearings of the two endpoints
+                const float fax = (float)sg[0], fay = (float)sg[1], fex = (float)sg[2], fey = (float)sg[3];
+                const float fbx = fax + fex, fby = fay + fey;
+                const float dmin = fast_sqrtf((float)edist[i]);
+                const float aa = fax * fax + fay * fay, bb = fbx * fbx + fby * fby;
+                if (aa < 1e-6f || bb < 1e-6f || dmin < 1e-3f) {
                     iv.y = R;  // an endpoint (or the edge) is on top of the vessel: bearings are meaningless
                 } else {
-                    const float xa = scan_index(fast_atan2f(fay, fax), (float)psi, inv_delta);
-                    const float xb = scan_index(fast_atan2f(fby, fbx), (float)psi, inv_delta);
+                    const float fpsi = (float)env[2 * TE + el];
+                    const float xa = scan_index(fast_atan2f(fay, fax), fpsi, inv_delta);
+                    const float xb = scan_index(fast_atan2f(fby, fbx), fpsi, inv_delta);
                     float d = xb - xa;
                     d = d > half_scan ? d - (float)R : d;
                     d = d < -half_scan ? d + (float)R : d;
@@ -664,47 +699,58 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                     }
                 }
             }
-            double* sg = seg + (size_t)i * (FIXED ? 4 : 5);
-            sg[0] = ax;
-            sg[1] = ay;
-            sg[2] = ex;
-            sg[3] = ey;
-            if (!FIXED) sg[4] = nt;
-            edist[i] = dd;
-            ecross_put(i, k == 0 ? (cross | (nv << 1)) : cross);  // edge 0 also carries the vertex count
-            AUV_CHECK(i >= 0 && i < TE * S && el >= 0 && el < ne && q >= 0 && q < P && iv.x >= 0 && iv.x < R && iv.y <= R);
-            meta[n_circ + i] = pack_meta(iv.x, iv.y, el, C + q);
         }
-        wave_append(iv.y, (unsigned int)(n_circ + i), &wsum[kCntEdge], true);
-    }
-    if (tid < ne) {
-        env[tid * 2] = env_c;
-        env[tid * 2 + 1] = env_s;
-    }
-    AUV_STAMP(2);
-    __syncthreads();
-    AUV_STAMP(3);
-    const int n_cp = wsum[kCntCircle], n_ep = wsum[kCntEdge];
-#ifdef AUV_PHASE_STAMPS
-    if (g_stamps && tid == 0) {
-        g_stamps[(size_t)blockIdx.x * 64 + 14] = n_cp;
-        g_stamps[(size_t)blockIdx.x * 64 + 15] = n_ep;
-    }
-#endif
-    const int total = n_cp + n_ep;
-    const bool fits = total <= cap;
-
-    // ---- phase 2: obstacle-level outputs.  Two tasks per obstacle, each on a
-    // wave of its own: 0 = distance (polygons: from their edges; also the
-    // deferred write-back of the advanced position) and the per-env summary;
-    // 1 = bearing, course, relative speed and risk, which share the bearing
-    // and the relative motion.  The kernel is bound by instruction issue, not by
-    // the length of one wave's chain: the other waves go straight to the sweeps.
+        AUV_CHECK(iv.x >= 0 && iv.x < R && iv.y >= 0 && iv.y <= R && el >= 0 && el < ne && oid >= 0 && oid < O);
+        Unit U;
+        U.incl = wave_inclusive_sum(iv.y);
+        U.excl = U.incl - iv.y;
+        U.total = __builtin_amdgcn_readlane(U.incl, 63);
+        // the compile-time shape fits the four in a word: 180 rays, 4 envs, 16 obstacles, 192 primitives
+        U.desc = FIXED ? (unsigned)iv.x | ((unsigned)el << 8) | ((unsigned)oid << 10) | ((unsigned)prim << 14)
+                       : (unsigned)iv.x | ((unsigned)prim << 16);
+        U.desc2 = (unsigned)el | ((unsigned)oid << 8);
+        return U;
+    };
+    auto unit_pair = [&](const Unit& U, int j) -> PairHit {
+        int lo4 = 0;  // 4 x the number of lanes whose pairs all come before pair j
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const int probe = __builtin_amdgcn_ds_bpermute(lo4 + (step - 1) * 4, U.incl);
+            lo4 = probe <= j ? lo4 + step * 4 : lo4;
+        }
+        const int k = j - __builtin_amdgcn_ds_bpermute(lo4, U.excl);
+        const unsigned int d = (unsigned int)__builtin_amdgcn_ds_bpermute(lo4, (int)U.desc);
+        int first, prim, el;
+        unsigned int oid;
+        if (FIXED) {
+            first = (int)(d & 0xffu);
+            el = (int)((d >> 8) & 3u);
+            oid = (d >> 10) & 15u;
+            prim = (int)(d >> 14);
+        } else {
+            const unsigned int d2 = (unsigned int)__builtin_amdgcn_ds_bpermute(lo4, (int)U.desc2);
+            first = (int)(d & 0xffffu);
+            prim = (int)(d >> 16);
+            el = (int)(d2 & 0xffu);
+            oid = d2 >> 8;
+        }
+        int r = first + k;
+        r = r >= R ? r - R : r;
+        PairHit h;
+        h.ok = false;
+        h.slot = 0;
+        h.oid = 0u;
+        h.key = 0ull;
+        if (j < U.total) {
+            AUV_CHECK(k >= 0 && r >= 0 && r < R && prim >= 0 && prim < n_circ + ne * S && el >= 0 && el < ne);
+            h = pair_test<FIXED>(prim, el, r, oid, R, n_circ, range, env, circ, seg, a.ray_dirs);
+            AUV_CHECK(!h.ok || (h.slot >= 0 && h.slot < ne * R && (int)h.oid < O));
+        }
+        return h;
+    };
     {
         const SenseArgs a2 = reload_args();
         const SenseArgs& a = a2;
-        const int n_waves = nthr >> 6;
-        const int wave = tid >> 6;
         const int n_obst = ne * O;
         // signed hull distance less the vessel radius; polygons: nearest edge
         // (sqrt of the smallest squared distance), sign from the crossing parity
@@ -735,7 +781,6 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         // when an env's obstacles sit in an aligned power-of-two group of lanes
         // of one wave, its nearest obstacle is a shuffle reduction
         const bool lanes_per_env = O > 0 && (O & (O - 1)) == 0 && TE * O <= 64;
-        const int n_tasks = a.with_meta ? 2 : 1;
         for (int task = wave; task < n_tasks; task += n_waves) {
             for (int i0 = 0; i0 < n_obst || (task == 0 && i0 == 0); i0 += 64) {
                 const int i = i0 + lane;
@@ -831,94 +876,59 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         }
     }
     AUV_STAMP(4);
-
-    // ---- phase 3: LiDAR sweeps (same barrier interval as phase 2: they share nothing)
-    if (fits) {
-        // the whole pair list is in LDS: the keys of sweep 0 stay in registers,
-        // sweep 1 does no arithmetic.  Pair w: circles first, then edges.  The
-        // waves that ran a task of phase 2 take no pairs when others are left: a
-        // task is longer than the rest's share of the sweep.
-        const int n_busy = a.with_meta ? 128 : 64;
-        const int sw0 = nthr > n_busy ? n_busy : 0;  // first sweeping thread
-        const int sw_n = nthr - sw0, sw_t = tid - sw0;
-        PairHit kept[kKeep];
+    // sweep 0: nearest hit of every ray.  The hits of the first rounds of the
+    // wave's first unit stay in registers for sweep 1, which settles the
+    // obstacle id among equal distances; whatever is beyond is walked again.
+    constexpr int kKeep = FIXED ? 6 : 4;
+    KeptHit<FIXED> kept[kKeep];
 #pragma unroll
-        for (int j = 0; j < kKeep; ++j) {
-            kept[j].ok = false;
-            const int w = sw_t + j * sw_n;
-            if (sw_t >= 0 && w < total) {
-                AUV_CHECK((w < n_cp ? w : cap - n_ep + (w - n_cp)) >= 0 && (w < n_cp ? w : cap - n_ep + (w - n_cp)) < cap);
-                kept[j] = pair_test<FIXED>(pair_get(w < n_cp ? w : cap - n_ep + (w - n_cp)), R, n_circ, range, meta, env, circ,
-                                    seg, a.ray_dirs);
-                AUV_CHECK(!kept[j].ok || (kept[j].slot >= 0 && kept[j].slot < ne * R && (int)kept[j].oid < O));
-                if (kept[j].ok) atomicMin(&best[kept[j].slot], kept[j].key);
-            }
-        }
-        for (int w = sw_t + kKeep * sw_n; sw_t >= 0 && w < total; w += sw_n) {
-            const PairHit h = pair_test<FIXED>(pair_get(w < n_cp ? w : cap - n_ep + (w - n_cp)), R, n_circ, range, meta, env,
-                                        circ, seg, a.ray_dirs);
-            if (h.ok) atomicMin(&best[h.slot], h.key);
-        }
-        AUV_STAMP(5);
-        __syncthreads();
-        AUV_STAMP(6);
+    for (int j = 0; j < kKeep; ++j) kept[j].clear();
+    bool walk_again = false;  // same for the whole wave
+    if (wave >= first_ray_wave) {
+        bool first_unit = true;
+        for (int u = wave - first_ray_wave; u < n_units; u += n_ray_waves) {
+            const Unit U = unit_open(u);
+            int j0 = 0;
+            if (first_unit) {
 #pragma unroll
-        for (int j = 0; j < kKeep; ++j)
-            if (kept[j].ok && best[kept[j].slot] == kept[j].key) atomicMin(&ids[kept[j].slot], kept[j].oid);
-        for (int w = sw_t + kKeep * sw_n; sw_t >= 0 && w < total; w += sw_n) {
-            const PairHit h = pair_test<FIXED>(pair_get(w < n_cp ? w : cap - n_ep + (w - n_cp)), R, n_circ, range, meta, env,
-                                        circ, seg, a.ray_dirs);
-            if (h.ok && best[h.slot] == h.key) atomicMin(&ids[h.slot], h.oid);
-        }
-        AUV_STAMP(7);
-        __syncthreads();
-        AUV_STAMP(8);
-    } else {
-        // more pairs than slots (dense scenes, vessel inside obstacles): rounds of
-        // `cap` pairs, each re-expanded from a prefix sum of the interval lengths
-        const int chunk = (NP + nthr - 1) / nthr;
-        const int p_lo = min(tid * chunk, NP), p_hi = min(p_lo + chunk, NP);
-        int mine = 0;
-        for (int p = p_lo; p < p_hi; ++p) mine += meta_count(meta[p]);
-        int incl = mine;
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += up;
-        }
-        if (lane == 63) wsum[tid >> 6] = incl;
-        __syncthreads();
-        int base = 0;
-        for (int wv = 0; wv < (tid >> 6); ++wv) base += wsum[wv];
-        int run = base + incl - mine;
-        for (int p = p_lo; p < p_hi; ++p) {
-            offs[p] = run;
-            run += meta_count(meta[p]);
-        }
-        __syncthreads();
-        const int n_rounds = (total + cap - 1) / cap;
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int rd = 0; rd < n_rounds; ++rd) {
-                const int w0 = rd * cap;
-                const int n_pairs = min(cap, total - w0);
-                for (int p = tid; p < NP; p += nthr) {
-                    const int o = offs[p];
-                    const int lo = max(o, w0), hi = min(o + meta_count(meta[p]), w0 + cap);
-                    AUV_CHECK(lo >= hi || (lo - w0 >= 0 && hi - w0 <= cap));
-                    for (int w = lo; w < hi; ++w) pair_put(w - w0, (unsigned int)p, (unsigned int)(w - o));
-                }
-                __syncthreads();
-                for (int w = tid; w < n_pairs; w += nthr) {
-                    const PairHit h = pair_test<FIXED>(pair_get(w), R, n_circ, range, meta, env, circ, seg, a.ray_dirs);
-                    if (h.ok) {
-                        AUV_CHECK(h.slot >= 0 && h.slot < ne * R && (int)h.oid < O);
-                        if (pass == 0) atomicMin(&best[h.slot], h.key);
-                        else if (best[h.slot] == h.key) atomicMin(&ids[h.slot], h.oid);
+                for (int j = 0; j < kKeep; ++j) {
+                    if (j * 64 < U.total) {
+                        const PairHit h = unit_pair(U, j * 64 + lane);
+                        if (h.ok) atomicMin(&best[h.slot], h.key);
+                        kept[j].set(h);
                     }
                 }
-                __syncthreads();
+                j0 = kKeep * 64;
+                first_unit = false;
+            }
+            for (; j0 < U.total; j0 += 64) {
+                const PairHit h = unit_pair(U, j0 + lane);
+                if (h.ok) atomicMin(&best[h.slot], h.key);
+                walk_again = true;
             }
         }
     }
+    AUV_STAMP(5);
+    __syncthreads();
+    AUV_STAMP(6);
+    // sweep 1
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j)
+        if (kept[j].ok() && best[kept[j].slot()] == kept[j].key) atomicMin(&ids[kept[j].slot()], kept[j].oid());
+    if (walk_again) {
+        bool first_unit = true;
+        for (int u = wave - first_ray_wave; u < n_units; u += n_ray_waves) {
+            const Unit U = unit_open(u);
+            for (int j0 = first_unit ? kKeep * 64 : 0; j0 < U.total; j0 += 64) {
+                const PairHit h = unit_pair(U, j0 + lane);
+                if (h.ok && best[h.slot] == h.key) atomicMin(&ids[h.slot], h.oid);
+            }
+            first_unit = false;
+        }
+    }
+    AUV_STAMP(7);
+    __syncthreads();
+    AUV_STAMP(8);
 
     // ---- phase 4: 16 B per ray, coalesced; the attached network's weights
     // come in meanwhile
@@ -959,10 +969,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
 }
 
 // DefaultShape.  A CU admits floor(800 / (scalar registers rounded up to 16, + 16)) workgroups of 256
-// threads: held to 96 scalar registers the kernel gets 7 per CU instead of 6, and its narrow LDS image
-// (23.0 KB) lets them in.
+// threads, 512 / (vector registers rounded up to 8) waves per SIMD and 160 KiB of LDS: held to 80 scalar
+// registers, with its 60-odd vector registers and its 19.4 KiB LDS image, the kernel gets 8 workgroups per CU,
+// which is every wave slot the CU has.
 template <int RISK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_sense_default(SenseArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_sense_default(SenseArgs a) {
     sense_tile<RISK, true>(a);
 }
 

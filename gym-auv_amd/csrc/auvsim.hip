@@ -109,7 +109,7 @@ struct auv_sim {
     int lidar_te = 1, lidar_block = 256, enc_eb = 1;
     size_t lidar_lds = 0, enc_lds = 0;
     int lidar_mode = AUV_LIDAR_RASTER;
-    int raster_te = 1, raster_cap = 2048, sense_block = 256;
+    int raster_te = 1, sense_block = 256;
     int raster_want = 0;  // envs per workgroup asked for (0 = automatic)
     int block_want = 0;   // threads per workgroup asked for (0 = automatic)
     int auto_reset = 0;   // done envs restart inside the next step
@@ -186,16 +186,6 @@ T* bp(auv_sim* h, int which) {
 // NULL is HIP's default (null) stream, exactly as in the HIP API itself
 hipStream_t pick(auv_sim*, void* stream) { return (hipStream_t)stream; }
 
-// Pair-list slots for a tile of `te` envs: room for ~12 candidate rays per
-// circle and ~3 per polygon edge (circles are the wide primitives) without a
-// second round, between 256 and 4096, a power of two.
-int pair_cap(const Dims& d, int te) {
-    const long long want = (long long)te * (12LL * d.C + 3LL * d.P * d.NV);
-    int cap = 256;
-    while (cap < 4096 && cap < want) cap <<= 1;
-    return cap;
-}
-
 // Tile of k_sense: `want` envs per workgroup, or (want <= 0) as many as keep
 // the LDS image under ~40 KiB (4 workgroups per CU) while the grid still has
 // >= 1024 workgroups.
@@ -203,7 +193,7 @@ void set_raster_tile(auv_sim* h, int want) {
     const Dims& d = h->d;
     const int S = d.P * d.NV;
     const int cf = (h->cnn_w && cnn_fits_sense_kernel(h->cnn_kind)) ? h->cnn_kind : -1;
-    auto bytes = [&](int te) { return sense_layout(te, d.R, d.C, d.P, d.NV, pair_cap(d, te), cf).total; };
+    auto bytes = [&](int te) { return sense_layout(te, d.R, d.C, d.P, d.NV, cf).total; };
     h->raster_want = want;
     int te = want;
     if (te <= 0) {
@@ -212,16 +202,13 @@ void set_raster_tile(auv_sim* h, int want) {
         while (te > 1 && (d.V + te - 1) / te < 1024) te >>= 1;
     }
     while (te > 1 && bytes(te) > kLdsMax) te >>= 1;
-    int cap = pair_cap(d, te);
-    while (cap > 256 && sense_layout(te, d.R, d.C, d.P, d.NV, cap, cf).total > kLdsMax) cap >>= 1;
     h->raster_te = te;
-    h->raster_cap = cap;
-    h->raster_lds = sense_layout(te, d.R, d.C, d.P, d.NV, cap, cf).total;
+    h->raster_lds = sense_layout(te, d.R, d.C, d.P, d.NV, cf).total;
     // a tile with many primitives (dense scenes) keeps 8 or 16 waves busy; the usual one is best with 4
     const long long prims = (long long)te * (d.C + S);
     h->sense_block = h->block_want ? h->block_want : (prims >= 1024 ? 1024 : prims >= 768 ? 512 : 256);
-    // the pair list packs (primitive, ray offset) into 16 bits each
-    if ((long long)te * (d.C + S) > 65535 || d.R > 65535) h->raster_lds = (size_t)1 << 30;
+    // the sweep carries first ray and primitive in 16 bits each, and the env of the tile in 8
+    if ((long long)te * (d.C + S) > 65535 || d.R > 65535 || te > 255) h->raster_lds = (size_t)1 << 30;
 }
 
 void choose_geometry(auv_sim* h) {
@@ -361,7 +348,6 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     SenseArgs sa;
     sa.d = d;
     sa.TE = h->raster_te;
-    sa.cap = h->raster_cap;
     sa.is_step = do_step;
     if (do_step) h->step_count++;
     sa.with_meta = !do_step || (h->meta_every > 0 && h->step_count % h->meta_every == 0);
@@ -407,15 +393,15 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.cnn_out = bp<float>(h, AUV_BUF_CNN_OUT);
     sa.cnn_kind = h->cnn_kind;
     {
-        const SenseLayout L = sense_layout(sa.TE, d.R, d.C, d.P, d.NV, sa.cap, sa.cnn_w ? sa.cnn_kind : -1);
-        const size_t off[12] = {L.env, L.circ, L.seg, L.best, L.obst, L.edist, L.meta, L.offs, L.ids, L.pairs, L.ecross, L.wsum};
-        for (int i = 0; i < 12; ++i) sa.lds[i] = (int)off[i];
+        const SenseLayout L = sense_layout(sa.TE, d.R, d.C, d.P, d.NV, sa.cnn_w ? sa.cnn_kind : -1);
+        const size_t off[10] = {L.env, L.circ, L.seg, L.best, L.obst, L.edist, L.ids, L.ecross, L.live, L.wsum};
+        for (int i = 0; i < 10; ++i) sa.lds[i] = (int)off[i];
     }
     sa.cnn_head = h->cnn_head;
     const int blocks = (d.V + h->raster_te - 1) / h->raster_te;
-    const bool fixed = is_default_shape(d, h->raster_te, h->sense_block, h->raster_cap);
+    const bool fixed = is_default_shape(d, h->raster_te, h->sense_block);
     // the compile-time shape has a narrower LDS image
-    const size_t lds_fixed = sense_layout(sa.TE, d.R, d.C, d.P, d.NV, sa.cap, sa.cnn_w ? sa.cnn_kind : -1, true).total;
+    const size_t lds_fixed = sense_layout(sa.TE, d.R, d.C, d.P, d.NV, sa.cnn_w ? sa.cnn_kind : -1, true).total;
     if (h->risk_model == AUV_RISK_REFERENCE) {
         if (fixed) hipLaunchKernelGGL(k_sense_default<1>, dim3(blocks), dim3(h->sense_block), lds_fixed, st, sa);
         else hipLaunchKernelGGL(k_sense<1>, dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
