@@ -629,8 +629,9 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     // ---- phase 2 and 3 share a barrier interval.  Phase 2, the obstacle-level
     // outputs, is two tasks, each on a wave of its own; the other waves (all of
     // them, when the workgroup has no more than that) run phase 3, the LiDAR
-    // sweep, in units of 64 primitives: the circles in thread order, then the
-    // listed edges.  A unit's wave gives each primitive its candidate rays
+    // sweep, in units of 64 primitives (fewer, down to 16, when that leaves waves
+    // without a unit): the circles in thread order, then the listed edges.  A
+    // unit's wave gives each primitive its candidate rays
     // [first, first + cnt), numbers the unit's (primitive, ray) pairs 0..total-1
     // in lane order and shares them out evenly: pair j goes to lane j % 64, which
     // finds the primitive by bisection over the running counts.  So the time goes
@@ -639,7 +640,11 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     const int first_ray_wave = n_waves > n_tasks ? n_tasks : 0;
     const int n_ray_waves = n_waves - first_ray_wave;
     const int n_live = wsum[kCntLive];
-    const int units_c = (n_circ + 63) >> 6, n_units = units_c + ((n_live + 63) >> 6);
+    int unit_shift = 6;  // log2 of the primitives per unit
+    if (!FIXED)
+        while (unit_shift > 4 && ((n_circ + n_live) >> unit_shift) < 2 * n_ray_waves) --unit_shift;
+    const int unit_prims = 1 << unit_shift;
+    const int units_c = (n_circ + unit_prims - 1) >> unit_shift, n_units = units_c + ((n_live + unit_prims - 1) >> unit_shift);
     struct Unit {
         int incl, excl, total;      // running count of pairs up to and with this lane's primitive, without it; all
         unsigned int desc, desc2;   // first ray, primitive, env and obstacle id of the lane's primitive
@@ -648,8 +653,8 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         int2 iv = make_int2(0, 0);
         int prim = 0, el = 0, oid = 0;
         if (u < units_c) {
-            const int i = u * 64 + lane;
-            if (i < n_circ) {
+            const int i = (u << unit_shift) + lane;
+            if (lane < unit_prims && i < n_circ) {
                 el = fast_div(i, inv_C);
                 oid = i - el * C;
                 prim = i;
@@ -669,8 +674,8 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                 }
             }
         } else {
-            const int j = (u - units_c) * 64 + lane;
-            if (j < n_live) {
+            const int j = ((u - units_c) << unit_shift) + lane;
+            if (lane < unit_prims && j < n_live) {
                 const int i = live_get(j);
                 AUV_CHECK(i >= 0 && i < ne * S);
                 el = fast_div(i, inv_S);

@@ -187,8 +187,9 @@ T* bp(auv_sim* h, int which) {
 hipStream_t pick(auv_sim*, void* stream) { return (hipStream_t)stream; }
 
 // Tile of k_sense: `want` envs per workgroup, or (want <= 0) as many as keep
-// the LDS image under ~40 KiB (4 workgroups per CU) while the grid still has
-// >= 1024 workgroups.
+// the LDS image within 24 KiB (6 workgroups per CU; 8 with the narrow image of
+// the compile-time shape) while the grid still has >= 2048 workgroups, one for
+// every workgroup slot of the device.
 void set_raster_tile(auv_sim* h, int want) {
     const Dims& d = h->d;
     const int S = d.P * d.NV;
@@ -198,15 +199,16 @@ void set_raster_tile(auv_sim* h, int want) {
     int te = want;
     if (te <= 0) {
         te = 16;
-        while (te > 1 && bytes(te) > 40u * 1024u) te >>= 1;
-        while (te > 1 && (d.V + te - 1) / te < 1024) te >>= 1;
+        while (te > 1 && bytes(te) > 24u * 1024u) te >>= 1;
+        while (te > 1 && (d.V + te - 1) / te < 2048) te >>= 1;
     }
     while (te > 1 && bytes(te) > kLdsMax) te >>= 1;
     h->raster_te = te;
     h->raster_lds = sense_layout(te, d.R, d.C, d.P, d.NV, cf).total;
-    // a tile with many primitives (dense scenes) keeps 8 or 16 waves busy; the usual one is best with 4
+    // waves per workgroup, from measurements: two for a tile of a few dozen primitives, four for the usual
+    // couple of hundred, twelve for the thousand of a dense scene
     const long long prims = (long long)te * (d.C + S);
-    h->sense_block = h->block_want ? h->block_want : (prims >= 1024 ? 1024 : prims >= 768 ? 512 : 256);
+    h->sense_block = h->block_want ? h->block_want : (prims >= 1024 ? 768 : prims >= 512 ? 512 : prims > 64 ? 256 : 128);
     // the sweep carries first ray and primitive in 16 bits each, and the env of the tile in 8
     if ((long long)te * (d.C + S) > 65535 || d.R > 65535 || te > 255) h->raster_lds = (size_t)1 << 30;
 }
@@ -1072,8 +1074,8 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
             h->lidar_mode = value;
             return AUV_OK;
         case AUV_OPT_SENSE_BLOCK:
-            if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
-                return fail(h, AUV_ERR_ARG, "auv_set_option: k_sense workgroup size must be 64, 128, 256, 512 or 1024");
+            if (value < 64 || value > 1024 || value % 64 != 0)
+                return fail(h, AUV_ERR_ARG, "auv_set_option: k_sense workgroup size must be a multiple of 64, 64 to 1024");
             h->block_want = value;
             h->sense_block = value;
             return AUV_OK;

@@ -114,8 +114,9 @@ typedef enum auv_buffer {
 typedef enum auv_option {
     AUV_OPT_LIDAR_MODE = 0,   /* AUV_LIDAR_RASTER (default) | AUV_LIDAR_ALL_PAIRS */
     AUV_OPT_RASTER_TILE = 1,  /* envs per workgroup of the rasterising kernel; 0 = auto */
-    AUV_OPT_SENSE_BLOCK = 2,  /* threads per k_sense workgroup: 64, 128, 256, 512 or 1024 (default: 256; 512 for
-                               * tiles of 768 primitives or more, 1024 from 1024 primitives) */
+    AUV_OPT_SENSE_BLOCK = 2,  /* threads per k_sense workgroup: a multiple of 64, 64 to 1024 (default by the
+                               * primitives, circles + edges, of a tile: 128 up to 64 of them, 256 up to 511,
+                               * 512 up to 1023, 768 beyond) */
     AUV_OPT_AUTO_RESET = 3,   /* 1: an env whose done flag is set restarts INSIDE the next auv_step, with no
                                * host round trip: its action is ignored, the vessel takes the initial state
                                * of the most recent auv_reset call, its step counter is cleared, its
