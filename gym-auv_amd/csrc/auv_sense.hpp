@@ -201,7 +201,8 @@ struct SenseLayout {
 //   env[TE][2] cos psi, sin psi, then [TE] psi      circ[TE*C][4] mx,my,cc,radius      seg[TE*S][5] ax,ay,ex,ey,nt
 //   best[TE*R] u64     obst: 5 fields [TE*O] mx,my,rvx,rvy,dist then 3 fields [TE*P] x,y,heading
 //                      (field-major: the lanes of a wave walk the banks)
-//   edist[TE*S] f64    ids[TE*R]   ecross[TE*S]   live[TE*S] numbers of the edges that have candidate rays   wsum[8]
+//   edist[TE*S] f64    ids[TE*R]   ecross[TE*S]   live[TE*S] numbers of the edges that have candidate rays,
+//   by blocks of 64 edges   wsum[blocks] how many each block lists
 // With a network evaluated in-kernel (cnn_kind >= 0) its weights and two
 // activation buffers per env reuse the bytes in front of best[], which are
 // dead by then; the front is padded when it is smaller than that.
@@ -227,7 +228,7 @@ __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P,
     L.ecross = o; o += (size_t)TE * S * (packed ? 1 : 4);
     L.live = o; o += (size_t)TE * S * (packed ? 1 : 2);
     o = (o + 3) & ~(size_t)3;
-    L.wsum = o; o += 8 * 4;
+    L.wsum = o; o += (((size_t)TE * S + 63) / 64 + 1) * 4;
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
@@ -368,7 +369,6 @@ __device__ unsigned long long g_violations = 0ull;
 #define AUV_CHECK(cond)
 #endif
 
-constexpr int kCntLive = 0;  // slot of wsum[] that counts the edges that have candidate rays
 
 // The scene shape of the reference's default scenario at the benchmark's size:
 // 180 rays (utils/dataloader.py:13), 8 circles + 8 five-vertex ships per env,
@@ -459,8 +459,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     const float inv_NV = __builtin_amdgcn_rcpf((float)NV), inv_O = __builtin_amdgcn_rcpf((float)(O > 0 ? O : 1));
 
     AUV_STAMP(0);
-    // ---- phase 0: accumulators
-    if (tid == 0) wsum[kCntLive] = 0;
+    // ---- phase 0: accumulators (first read after the barrier that ends phase 1)
     // heading (and its sin/cos) of the tile's vessels: requested now, filed at the
     // end of phase 1, so that the first barrier does not wait for global memory
     double env_c = 0.0, env_s = 0.0, env_psi = 0.0;
@@ -475,7 +474,6 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         best[f] = range_bits;
         ids[f] = 0xffffffffu;
     }
-    __syncthreads();
     AUV_STAMP(1);
 
     // ---- phase 1: geometry of the primitives.  Circles go to the highest
@@ -521,7 +519,8 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     // Edges: geometry, distance and crossing bit of every edge; the few that a
     // ray can hit at all (in range, facing the vessel) are listed, and get their
     // candidate rays after the barrier from one wave instead of occupying a lane
-    // in every wave here.
+    // in every wave here.  Every block of 64 edges has a list and a count of its
+    // own: no counter is shared, so nothing has to be zeroed behind a barrier.
     for (int ib = 0; ib < ne * S; ib += nthr) {
         if (ib + wave0 >= ne * S) continue;  // nothing for this wave
         const int i = ib + tid;
@@ -608,14 +607,11 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
             AUV_CHECK(i >= 0 && i < TE * S && el >= 0 && el < ne && q >= 0 && q < P);
         }
         const unsigned long long found = __ballot(has_rays);
-        if (found != 0ull) {  // same for the whole wave
-            int at = 0;
-            if (lane == 0) at = atomicAdd(&wsum[kCntLive], __popcll(found));
-            at = __builtin_amdgcn_readfirstlane(at) +
-                 (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(found >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)found, 0u));
-            AUV_CHECK(!has_rays || (at >= 0 && at < TE * S));
-            if (has_rays) live_put(at, i);
-        }
+        const int at = ib + wave0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(found >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((unsigned int)found, 0u));
+        AUV_CHECK(!has_rays || (at >= 0 && at < TE * S));
+        if (has_rays) live_put(at, i);
+        if (lane == 0) wsum[(ib + wave0) >> 6] = __popcll(found);
     }
     if (tid < ne) {
         env[tid * 2] = env_c;
@@ -629,9 +625,8 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     // ---- phase 2 and 3 share a barrier interval.  Phase 2, the obstacle-level
     // outputs, is two tasks, each on a wave of its own; the other waves (all of
     // them, when the workgroup has no more than that) run phase 3, the LiDAR
-    // sweep, in units of 64 primitives (fewer, down to 16, when that leaves waves
-    // without a unit): the circles in thread order, then the listed edges.  A
-    // unit's wave gives each primitive its candidate rays
+    // sweep, in units of 64 primitives: the circles in thread order, then the
+    // listed edges.  A unit's wave gives each primitive its candidate rays
     // [first, first + cnt), numbers the unit's (primitive, ray) pairs 0..total-1
     // in lane order and shares them out evenly: pair j goes to lane j % 64, which
     // finds the primitive by bisection over the running counts.  So the time goes
@@ -639,12 +634,12 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     const int n_tasks = a.with_meta ? 2 : 1;
     const int first_ray_wave = n_waves > n_tasks ? n_tasks : 0;
     const int n_ray_waves = n_waves - first_ray_wave;
-    const int n_live = wsum[kCntLive];
-    int unit_shift = 6;  // log2 of the primitives per unit
-    if (!FIXED)
-        while (unit_shift > 4 && ((n_circ + n_live) >> unit_shift) < 2 * n_ray_waves) --unit_shift;
-    const int unit_prims = 1 << unit_shift;
-    const int units_c = (n_circ + unit_prims - 1) >> unit_shift, n_units = units_c + ((n_live + unit_prims - 1) >> unit_shift);
+    const int n_blocks = (ne * S + 63) >> 6;
+    int n_live = 0;
+    for (int b = 0; b < n_blocks; ++b) n_live += wsum[b];
+    const int units_c = (n_circ + 63) >> 6, n_units = units_c + ((n_live + 63) >> 6);
+    // with waves to spare, several open the same unit and deal its rounds among them
+    const int n_share = (FIXED || n_units == 0 || n_ray_waves < 2 * n_units) ? 1 : n_ray_waves / n_units;
     struct Unit {
         int incl, excl, total;      // running count of pairs up to and with this lane's primitive, without it; all
         unsigned int desc, desc2;   // first ray, primitive, env and obstacle id of the lane's primitive
@@ -653,8 +648,8 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         int2 iv = make_int2(0, 0);
         int prim = 0, el = 0, oid = 0;
         if (u < units_c) {
-            const int i = (u << unit_shift) + lane;
-            if (lane < unit_prims && i < n_circ) {
+            const int i = (u << 6) + lane;
+            if (i < n_circ) {
                 el = fast_div(i, inv_C);
                 oid = i - el * C;
                 prim = i;
@@ -674,9 +669,16 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                 }
             }
         } else {
-            const int j = ((u - units_c) << unit_shift) + lane;
-            if (lane < unit_prims && j < n_live) {
-                const int i = live_get(j);
+            const int j = ((u - units_c) << 6) + lane;
+            if (j < n_live) {
+                // the j-th listed edge: walk the blocks' counts
+                int b = 0, before = 0;
+                for (int nb = wsum[0]; j >= before + nb; nb = wsum[b]) {
+                    before += nb;
+                    ++b;
+                }
+                AUV_CHECK(b >= 0 && b < n_blocks);
+                const int i = live_get((b << 6) + (j - before));
                 AUV_CHECK(i >= 0 && i < ne * S);
                 el = fast_div(i, inv_S);
                 oid = C + fast_div(i - el * S, inv_NV);
@@ -891,22 +893,23 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     bool walk_again = false;  // same for the whole wave
     if (wave >= first_ray_wave) {
         bool first_unit = true;
-        for (int u = wave - first_ray_wave; u < n_units; u += n_ray_waves) {
+        for (int w = wave - first_ray_wave; w < n_units * n_share; w += n_ray_waves) {
+            const int u = FIXED ? w : w / n_share, part = FIXED ? 0 : w - u * n_share;  // rounds part, part + n_share, ...
             const Unit U = unit_open(u);
-            int j0 = 0;
+            int j0 = part * 64;
             if (first_unit) {
 #pragma unroll
                 for (int j = 0; j < kKeep; ++j) {
-                    if (j * 64 < U.total) {
-                        const PairHit h = unit_pair(U, j * 64 + lane);
+                    if (j0 < U.total) {
+                        const PairHit h = unit_pair(U, j0 + lane);
                         if (h.ok) atomicMin(&best[h.slot], h.key);
                         kept[j].set(h);
                     }
+                    j0 += n_share * 64;
                 }
-                j0 = kKeep * 64;
                 first_unit = false;
             }
-            for (; j0 < U.total; j0 += 64) {
+            for (; j0 < U.total; j0 += n_share * 64) {
                 const PairHit h = unit_pair(U, j0 + lane);
                 if (h.ok) atomicMin(&best[h.slot], h.key);
                 walk_again = true;
@@ -922,9 +925,10 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         if (kept[j].ok() && best[kept[j].slot()] == kept[j].key) atomicMin(&ids[kept[j].slot()], kept[j].oid());
     if (walk_again) {
         bool first_unit = true;
-        for (int u = wave - first_ray_wave; u < n_units; u += n_ray_waves) {
+        for (int w = wave - first_ray_wave; w < n_units * n_share; w += n_ray_waves) {
+            const int u = FIXED ? w : w / n_share, part = FIXED ? 0 : w - u * n_share;
             const Unit U = unit_open(u);
-            for (int j0 = first_unit ? kKeep * 64 : 0; j0 < U.total; j0 += 64) {
+            for (int j0 = (part + (first_unit ? kKeep * n_share : 0)) * 64; j0 < U.total; j0 += n_share * 64) {
                 const PairHit h = unit_pair(U, j0 + lane);
                 if (h.ok && best[h.slot] == h.key) atomicMin(&ids[h.slot], h.oid);
             }
