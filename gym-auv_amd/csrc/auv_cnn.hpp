@@ -98,10 +98,13 @@ __device__ __forceinline__ void layer_sync() {
 // every kernel that evaluates it): one partial sum per sector, taps in order
 // from 0, then ((bias + s0) + s1) + s2.  Sector sums are independent work
 // items (stage A, into `tmp`: Cout*36 floats per scan), combined after a sync
-// (stage B, into `out`); a sector never wraps, 180 being 12 sectors.
+// (stage B, into `out`); a sector never wraps, 180 being 12 sectors.  With
+// `rows` the layer is the network's last: its Cout*12 values per scan also go
+// to rows + s*Cout*12 (global), from the thread that formed them.
 template <bool RELU, bool BLOCK>
 __device__ __forceinline__ void conv_sectors(const float* x, int x_stride, float* out, float* tmp, int a_stride, int ns,
-                                             const float* w, const float* b, int Cout, int worker, int n_workers) {
+                                             const float* w, const float* b, int Cout, int worker, int n_workers,
+                                             float* rows = nullptr) {
     if (!BLOCK) {
         // few lanes per scan: each keeps the three sector sums of its outputs in
         // registers (same order of operations, no staging)
@@ -125,6 +128,7 @@ __device__ __forceinline__ void conv_sectors(const float* x, int x_stride, float
             float acc = ((b[co] + part[0]) + part[1]) + part[2];
             if (RELU) acc = acc > 0.f ? acc : 0.f;
             out[(size_t)s * a_stride + col] = acc;
+            if (rows) rows[(size_t)s * (Cout * 12) + col] = acc;
         }
         return;
     }
@@ -153,6 +157,7 @@ __device__ __forceinline__ void conv_sectors(const float* x, int x_stride, float
         float acc = ((b[col / 12] + t[0]) + t[1]) + t[2];
         if (RELU) acc = acc > 0.f ? acc : 0.f;
         out[(size_t)s * a_stride + col] = acc;
+        if (rows) rows[(size_t)s * (Cout * 12) + col] = acc;
     }
 }
 
@@ -199,9 +204,9 @@ __device__ __forceinline__ void cnn_forward(const float* x, int x_stride, float*
     if (kind == CNN_SHALLOW) {
         // w: conv.weight[45] conv.bias[1] linear.weight[12] linear.bias[1]
         if (head == HEAD_FEATURES) {
-            conv_sectors<false, BLOCK>(x, x_stride, p, q, a_stride, ns, w, w + 45, 1, worker, n_workers);
-            res = p;
-            n_res = 12;
+            // the one layer is the result: stored as it is formed, no copy behind another sync
+            conv_sectors<false, BLOCK>(x, x_stride, p, q, a_stride, ns, w, w + 45, 1, worker, n_workers, out);
+            return;
         } else {
             conv_sectors<true, BLOCK>(x, x_stride, p, q, a_stride, ns, w, w + 45, 1, worker, n_workers);
             layer_sync<BLOCK>();

@@ -203,12 +203,10 @@ struct SenseLayout {
 //                      (field-major: the lanes of a wave walk the banks)
 //   edist[TE*S] f64    ids[TE*R]   ecross[TE*S]   live[TE*S] numbers of the edges that have candidate rays,
 //   by blocks of 64 edges   wsum[blocks] how many each block lists
-// With a network evaluated in-kernel (cnn_kind >= 0) its weights and two
-// activation buffers per env reuse the bytes in front of best[], which are
-// dead by then; the front is padded when it is smaller than that.
-__host__ __device__ inline size_t sense_cnn_bytes(int TE, int cnn_kind) {
-    return cnn_kind < 0 ? 0 : ((size_t)((cnn_n_weights(cnn_kind) + 3) & ~3) + (size_t)TE * cnn_act_floats(cnn_kind)) * 4;
-}
+// With a network evaluated in-kernel (cnn_kind >= 0) its input (R floats per env)
+// and its weights reuse the bytes of obst[], and its two activation buffers
+// per env those of best[], both dead by then; the regions are padded when
+// they are smaller than that.
 // packed: the narrow image of the compile-time shape (DefaultShape): edges without their stored cross
 // product, 8-bit crossing records and edge numbers.
 __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P, int NV, int cnn_kind, bool packed = false) {
@@ -218,11 +216,11 @@ __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P,
     L.env = o; o += (size_t)TE * 3 * 8;
     L.circ = o; o += (size_t)TE * C * 4 * 8;
     L.seg = o; o += (size_t)TE * S * (packed ? 4 : 5) * 8;
-    const size_t act = sense_cnn_bytes(TE, cnn_kind);
-    o = o < act ? act : o;
-    o = (o + 7) & ~(size_t)7;
-    L.best = o; o += (size_t)TE * R * 8;
-    L.obst = o; o += ((size_t)TE * O * 5 + (size_t)TE * P * 3) * 8;
+    const size_t act = cnn_kind < 0 ? 0 : (size_t)TE * cnn_act_floats(cnn_kind) * 4;
+    const size_t xw = cnn_kind < 0 ? 0 : (((size_t)TE * R + cnn_n_weights(cnn_kind)) * 4 + 7) & ~(size_t)7;
+    const size_t bb = (size_t)TE * R * 8, ob = ((size_t)TE * O * 5 + (size_t)TE * P * 3) * 8;
+    L.best = o; o += bb > act ? bb : act;
+    L.obst = o; o += ob > xw ? ob : xw;
     L.edist = o; o += (size_t)TE * S * 8;
     L.ids = o; o += (size_t)TE * R * 4;
     L.ecross = o; o += (size_t)TE * S * (packed ? 1 : 4);
@@ -919,6 +917,17 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     AUV_STAMP(5);
     __syncthreads();
     AUV_STAMP(6);
+    // ---- phase 4: per-ray outputs, 16 B per ray, coalesced.  The distances
+    // are final, so ranges and closeness go out now, beside sweep 1; with a
+    // network attached its input and its weights are filed in the bytes of
+    // obst[], which phase 2 is done with.
+    const SenseArgs a4 = reload_args();
+    const SenseArgs& a_out = a4;
+    float* cnn_x = reinterpret_cast<float*>(lds_raw + L.obst);  // [TE][R] closeness, then the weights
+    float* cnn_wl = cnn_x + TE * R;
+    const int n_w = a_out.cnn_w ? cnn_n_weights(a_out.cnn_kind) : 0;
+    float w_mine = 0.f;
+    if (tid < n_w) w_mine = a_out.cnn_w[tid];
     // sweep 1
 #pragma unroll
     for (int j = 0; j < kKeep; ++j)
@@ -935,36 +944,28 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
             first_unit = false;
         }
     }
-    AUV_STAMP(7);
-    __syncthreads();
-    AUV_STAMP(8);
-
-    // ---- phase 4: 16 B per ray, coalesced; the attached network's weights
-    // come in meanwhile
-    const SenseArgs a4 = reload_args();
-    const SenseArgs& a_out = a4;
-    float* cnn_lds = reinterpret_cast<float*>(lds_raw);  // weights, then 2 activation buffers per env
-    const int n_w = a_out.cnn_w ? cnn_n_weights(a_out.cnn_kind) : 0;
-    float w_mine = 0.f;
-    if (tid < n_w) w_mine = a_out.cnn_w[tid];
     for (int f = tid; f < ne * R; f += nthr) {
         const double t = __longlong_as_double((long long)best[f]);
         const size_t out = (size_t)e0 * R + f;
         const float close = (float)(1.0 - div_by_const(t, range, a_out.inv_range));
         __builtin_nontemporal_store(t, &a_out.ranges[out]);
-        __builtin_nontemporal_store((int)ids[f], &a_out.hit[out]);
         __builtin_nontemporal_store(close, &a_out.perception[out]);
-        if (a_out.cnn_w) reinterpret_cast<float*>(ids)[f] = close;  // the id slot becomes the network's input
+        if (a_out.cnn_w) cnn_x[f] = close;
     }
     if (a_out.cnn_w) {
-        if (tid < n_w) cnn_lds[tid] = w_mine;
-        for (int i = tid + nthr; i < n_w; i += nthr) cnn_lds[i] = a_out.cnn_w[i];
-        __syncthreads();
+        if (tid < n_w) cnn_wl[tid] = w_mine;
+        for (int i = tid + nthr; i < n_w; i += nthr) cnn_wl[i] = a_out.cnn_w[i];
+    }
+    AUV_STAMP(7);
+    __syncthreads();
+    AUV_STAMP(8);
+    for (int f = tid; f < ne * R; f += nthr) __builtin_nontemporal_store((int)ids[f], &a_out.hit[(size_t)e0 * R + f]);
+    if (a_out.cnn_w) {
         // the tile's scans together, output elements dealt over the workgroup;
-        // each is summed by one thread in the order k_cnn uses: same values
-        float* act = cnn_lds + ((n_w + 3) & ~3);
-        cnn_forward<false, true>(reinterpret_cast<const float*>(ids), R, act, act + cnn_p_floats(a_out.cnn_kind),
-                                 cnn_act_floats(a_out.cnn_kind), ne, cnn_lds,
+        // each is summed by one thread in the order k_cnn uses: same values.
+        // The activation buffers take the bytes of best[], read for the last time above.
+        float* act = reinterpret_cast<float*>(best);
+        cnn_forward<false, true>(cnn_x, R, act, act + cnn_p_floats(a_out.cnn_kind), cnn_act_floats(a_out.cnn_kind), ne, cnn_wl,
                                  a_out.cnn_out + (size_t)e0 * cnn_out_dim(a_out.cnn_kind, a_out.cnn_head), a_out.cnn_kind,
                                  a_out.cnn_head, tid, nthr);
     }
