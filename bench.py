@@ -69,6 +69,14 @@ def cpu_baseline(name, n_envs, steps, threads, scalar_envs=4):
     from oracle import c_oracle
     from tests.helpers import make_oracle
 
+    from gym_auv_amd.scenarios import WORKLOADS
+    wl = WORKLOADS[name]
+    per_env = wl["R"] * (wl["C"] + wl["P"] * wl["NV"])  # ray-primitive pairs of one env
+    # every leg is sized by the scene: the pairs of `steps` steps of the default scene (8,640 per env) at most
+    budget = n_envs * steps * 8640 // per_env  # env-steps
+    steps = max(5, min(steps, budget // n_envs))
+    n_envs = max(16 * threads, min(n_envs, budget // steps))
+    print(f"[bench] cpu baseline: C oracle, {n_envs} envs x {steps} steps, {threads} threads", file=sys.stderr, flush=True)
     cfg, scene = scenarios.make_workload(name, n_envs=n_envs)
     env = c_oracle.COracleEnv(cfg, params.ray_table(cfg["n_rays"]), threads=threads)
     env.set_scene(scene["circles"], scene["poly_pose"], scene["poly_verts"], scene["poly_nv"],
@@ -82,11 +90,9 @@ def cpu_baseline(name, n_envs, steps, threads, scalar_envs=4):
     dt = time.perf_counter() - t0
     env.close()
     # the numpy legs are sized by the scene: about as many ray-primitive pairs as 2,048 envs of the default scene
-    per_env = w_prims = None
-    from gym_auv_amd.scenarios import WORKLOADS
-    wl = WORKLOADS[name]
-    per_env = wl["R"] * (wl["C"] + wl["P"] * wl["NV"])
     n_np, s_np = max(16, min(n_envs, 2048, int(2048 * 8640 / per_env))), min(steps, 10)
+    print(f"[bench] cpu baseline: numpy oracle, {n_np} envs x {s_np} steps, then one object per env", file=sys.stderr,
+          flush=True)
     cfg2, scene2 = scenarios.make_workload(name, n_envs=n_np)
     env2 = make_oracle(cfg2, scene2)
     env2.reset(scene2["init_state"])
