@@ -57,7 +57,7 @@ EXPORTS = (
     "auv_profile_enable", "auv_cnn_n_weights", "auv_cnn_out_dim", "auv_cnn_create", "auv_cnn_destroy",
     "auv_cnn_forward", "auv_cnn_last_error", "auv_format_rows",
     "auv_profile_read", "auv_attach_cnn", "auv_generate_scene", "auv_host_alloc", "auv_host_free",
-    "auv_risk_rows", "auv_episode_stats", "auv_episode_stats_static", "auv_train_shallow", "auv_set_path",
+    "auv_risk_rows", "auv_episode_stats", "auv_episode_stats_static", "auv_train_shallow", "auv_train_cnn", "auv_set_path",
 )
 
 
@@ -176,6 +176,8 @@ def load():
     lib.auv_episode_stats_static.argtypes = [vp, vp, i32, vp]
     lib.auv_train_shallow.restype = C.c_int
     lib.auv_train_shallow.argtypes = [C.c_int, vp, vp, i64, vp, i64, i32, vp, vp, C.POINTER(AuvTrainParams), i64, vp, vp]
+    lib.auv_train_cnn.restype = C.c_int
+    lib.auv_train_cnn.argtypes = [i32] + lib.auv_train_shallow.argtypes
     lib.auv_set_path.restype = C.c_int
     lib.auv_set_path.argtypes = [vp, i32, i32, vp, i32, vp]
     _lib = lib

@@ -21,7 +21,7 @@ constexpr int kCnnLanes = 16;        // lanes per scan
 constexpr int kCnnScans = 16;        // scans per 256-thread workgroup
 constexpr int kCnnBuf = 184;         // floats per activation buffer (>= 180, 16-B multiple)
 
-__host__ __device__ inline int cnn_n_weights(int kind) {
+__host__ __device__ constexpr int cnn_n_weights(int kind) {
     return kind == CNN_SHALLOW ? 59 : kind == CNN_2DEEP ? 178 : 3723;
 }
 __host__ __device__ inline int cnn_out_dim(int kind, int head) {

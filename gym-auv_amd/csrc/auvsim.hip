@@ -1326,44 +1326,87 @@ int auv_cnn_forward(auv_cnn_handle c, const float* scans, int64_t n_scans, int32
     return AUV_OK;
 }
 
-int auv_train_shallow(int device, const float* X, const float* y, int64_t n_rows, const int32_t* perm,
-                      int64_t n_batches, int32_t batch, float* weights, float* opt_state,
-                      const auv_train_params* hp, int64_t steps_done, float* batch_loss, void* stream) {
+namespace {
+// checks shared by the training entry points; fills the kernel's argument block
+int train_args(const char* who, int device, const float* X, const float* y, int64_t n_rows, const int32_t* perm,
+               int64_t n_batches, int32_t batch, float* weights, float* opt_state, const auv_train_params* hp,
+               int64_t steps_done, float* batch_loss, TrainArgs* a) {
     if (!X || !y || !perm || !weights || !opt_state || !hp || !batch_loss)
-        return cnn_fail(nullptr, AUV_ERR_ARG, "auv_train_shallow: null argument");
+        return cnn_fail(nullptr, AUV_ERR_ARG, "%s: null argument", who);
     if (batch < 1 || batch > AUV_TRAIN_BATCH_MAX)
-        return cnn_fail(nullptr, AUV_ERR_ARG, "auv_train_shallow: batch must be in 1..%d, got %d", AUV_TRAIN_BATCH_MAX, batch);
+        return cnn_fail(nullptr, AUV_ERR_ARG, "%s: batch must be in 1..%d, got %d", who, AUV_TRAIN_BATCH_MAX, batch);
     if (n_rows < 1 || n_batches < 0 || steps_done < 0)
-        return cnn_fail(nullptr, AUV_ERR_ARG, "auv_train_shallow: n_rows must be >= 1, n_batches and steps_done >= 0");
+        return cnn_fail(nullptr, AUV_ERR_ARG, "%s: n_rows must be >= 1, n_batches and steps_done >= 0", who);
     if (hp->optimizer != AUV_OPT_ADAMW && hp->optimizer != AUV_OPT_SGD_MOMENTUM)
-        return cnn_fail(nullptr, AUV_ERR_ARG, "auv_train_shallow: unknown optimizer %d", hp->optimizer);
-    if (!(hp->lr > 0.0)) return cnn_fail(nullptr, AUV_ERR_ARG, "auv_train_shallow: lr must be positive");
+        return cnn_fail(nullptr, AUV_ERR_ARG, "%s: unknown optimizer %d", who, hp->optimizer);
+    if (!(hp->lr > 0.0)) return cnn_fail(nullptr, AUV_ERR_ARG, "%s: lr must be positive", who);
     if (n_batches == 0) return AUV_OK;
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
-        return cnn_fail(nullptr, AUV_ERR_DEVICE, "auv_train_shallow: no HIP device %d", device);
+        return cnn_fail(nullptr, AUV_ERR_DEVICE, "%s: no HIP device %d", who, device);
     if (hipSetDevice(device) != hipSuccess) return cnn_fail(nullptr, AUV_ERR_DEVICE, "hipSetDevice failed");
+    a->X = X;
+    a->y = y;
+    a->perm = perm;
+    a->n_batches = n_batches;
+    a->batch = batch;
+    a->optimizer = hp->optimizer;
+    a->step0 = steps_done;
+    a->w = weights;
+    a->opt = opt_state;
+    a->batch_loss = batch_loss;
+    a->lr = hp->lr;
+    a->beta1 = hp->beta1;
+    a->beta2 = hp->beta2;
+    a->eps = hp->eps;
+    a->weight_decay = hp->weight_decay;
+    a->momentum = hp->momentum;
+    return AUV_OK;
+}
+
+extern "C++" template <int KIND>
+int launch_train_net(const TrainArgs& a, hipStream_t stream) {
+    constexpr size_t lds = train_net_lds_bytes(KIND);
+    static_assert(lds <= kLdsMax, "the batch's activations and gradients must fit the CU's LDS");
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_net<KIND>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return cnn_fail(nullptr, AUV_ERR_DEVICE, "k_train_net: %zu B of LDS refused: %s", lds, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k_train_net<KIND>, dim3(1), dim3(kTrainNetThreads), lds, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cnn_fail(nullptr, AUV_ERR_DEVICE, "k_train_net launch failed: %s", hipGetErrorString(e));
+    return AUV_OK;
+}
+}  // namespace
+
+int auv_train_shallow(int device, const float* X, const float* y, int64_t n_rows, const int32_t* perm,
+                      int64_t n_batches, int32_t batch, float* weights, float* opt_state,
+                      const auv_train_params* hp, int64_t steps_done, float* batch_loss, void* stream) {
     TrainArgs a;
-    a.X = X;
-    a.y = y;
-    a.perm = perm;
-    a.n_batches = n_batches;
-    a.batch = batch;
-    a.optimizer = hp->optimizer;
-    a.step0 = steps_done;
-    a.w = weights;
-    a.opt = opt_state;
-    a.batch_loss = batch_loss;
-    a.lr = hp->lr;
-    a.beta1 = hp->beta1;
-    a.beta2 = hp->beta2;
-    a.eps = hp->eps;
-    a.weight_decay = hp->weight_decay;
-    a.momentum = hp->momentum;
+    const int rc = train_args("auv_train_shallow", device, X, y, n_rows, perm, n_batches, batch, weights, opt_state, hp,
+                              steps_done, batch_loss, &a);
+    if (rc != AUV_OK || n_batches == 0) return rc;
     hipLaunchKernelGGL(k_train_shallow, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cnn_fail(nullptr, AUV_ERR_DEVICE, "k_train_shallow launch failed: %s", hipGetErrorString(e));
     return AUV_OK;
+}
+
+int auv_train_cnn(int32_t kind, int device, const float* X, const float* y, int64_t n_rows, const int32_t* perm,
+                  int64_t n_batches, int32_t batch, float* weights, float* opt_state, const auv_train_params* hp,
+                  int64_t steps_done, float* batch_loss, void* stream) {
+    if (kind < AUV_CNN_SHALLOW || kind > AUV_CNN_DEEP)
+        return cnn_fail(nullptr, AUV_ERR_ARG, "auv_train_cnn: unknown network %d", kind);
+    if (kind == AUV_CNN_SHALLOW)
+        return auv_train_shallow(device, X, y, n_rows, perm, n_batches, batch, weights, opt_state, hp, steps_done,
+                                 batch_loss, stream);
+    TrainArgs a;
+    const int rc = train_args("auv_train_cnn", device, X, y, n_rows, perm, n_batches, batch, weights, opt_state, hp,
+                              steps_done, batch_loss, &a);
+    if (rc != AUV_OK || n_batches == 0) return rc;
+    return kind == AUV_CNN_2DEEP ? launch_train_net<CNN_2DEEP>(a, (hipStream_t)stream)
+                                 : launch_train_net<CNN_DEEP>(a, (hipStream_t)stream);
 }
 
 int auv_risk_rows(auv_handle h, int64_t n, const double* own_speed, const double* own_heading,

@@ -48,28 +48,36 @@ class Trainer:
 
 
 class DeviceTrainer:
-    """`Trainer` for the one-convolution network with the data resident on the
-    GPU: every epoch's batches (trainer.py:80-83) run in one launch of the
-    library's fused training kernel (`auv_train_shallow`: forward, MSE,
-    backward and the optimizer step of trainer.py:44-53 per batch, parameters
-    and optimizer state on chip), instead of ~10 small launches per batch.
+    """`Trainer` with the data resident on the GPU: every epoch's batches
+    (trainer.py:80-83) run in one launch of the library's fused training
+    kernel (`auv_train_cnn`: forward, MSE, backward and the optimizer step of
+    trainer.py:44-53 per batch, parameters and optimizer state on chip),
+    instead of 10 to 150 small launches per batch.
 
     X_* float32 [n,1,180] or [n,180] closeness scans and y_* float32 [n] or
-    [n,1] labels, numpy or torch (copied to the device once).  `model` is a
-    `models.LidarCNNShallow`; its parameters are read at construction and
-    written back after every epoch, so `model.state_dict()` feeds
-    `cnn.LidarCNN` (the HIP inference path) as before."""
+    [n,1] labels, numpy or torch (copied to the device once).  `model` is one
+    of `models.LidarCNNShallow`, `LidarCNN2Deep` or `LidarCNNDeep` (with the
+    default channels and kernel, the configuration of trainer.py:144); its
+    parameters are read at construction and written back after every epoch,
+    so `model.state_dict()` feeds `cnn.LidarCNN` (the HIP inference path) as
+    before."""
 
     def __init__(self, model, epochs: int, learning_rate: float, X_train, y_train, X_val=None, y_val=None,
                  optimizer: str = "adamw", batch_size: int = 16, seed: int = 2, device: int = 0):
         import ctypes as C
 
         from . import _lib
-        from .cnn import STATE_KEYS, pack_weights
+        from .cnn import KINDS, STATE_KEYS, pack_weights
+        from .models import MODELS
 
         self._lib, self._C, self._api = _lib.load(), C, _lib
         if not 1 <= batch_size <= _lib.TRAIN_BATCH_MAX:
             raise ValueError(f"batch_size must be in 1..{_lib.TRAIN_BATCH_MAX}")
+        kinds = [k for k, cls in MODELS.items() if type(model) is cls]
+        if not kinds:
+            raise TypeError(f"DeviceTrainer trains {', '.join(c.__name__ for c in MODELS.values())}; got {type(model).__name__}")
+        self.kind = kinds[0]
+        self._kind_id = KINDS[self.kind]
         self.model, self.epochs, self.device = model, int(epochs), int(device)
         self.batch_size = int(batch_size)
         dev = torch.device("cuda", self.device)
@@ -80,8 +88,12 @@ class DeviceTrainer:
         self.yv = None if y_val is None else as_dev(y_val, (-1,))
         if len(self.X) != len(self.y):
             raise ValueError("X_train and y_train differ in length")
-        self._keys = STATE_KEYS["shallow"]
-        self.w = torch.from_numpy(pack_weights("shallow", model.state_dict())).to(dev)
+        self._keys = STATE_KEYS[self.kind]
+        packed = pack_weights(self.kind, model.state_dict())
+        if packed.size != self._lib.auv_cnn_n_weights(self._kind_id):
+            raise ValueError(f"{type(model).__name__} has {packed.size} parameters; the library's {self.kind} network has "
+                             f"{self._lib.auv_cnn_n_weights(self._kind_id)} (default channels and kernel only)")
+        self.w = torch.from_numpy(packed).to(dev)
         self.opt_state = torch.zeros(2 * self.w.numel(), dtype=torch.float32, device=dev)
         self.hp = _lib.AuvTrainParams(optimizer=_lib.OPT_SGD_MOMENTUM if optimizer == "sgd" else _lib.OPT_ADAMW,
                                       reserved=0, lr=float(learning_rate), beta1=0.9, beta2=0.999, eps=1e-8,
@@ -102,9 +114,9 @@ class DeviceTrainer:
         losses = torch.empty(n_batches, dtype=torch.float32, device=self.X.device)
         st = torch.cuda.current_stream(self.X.device).cuda_stream
         p = lambda t: C.c_void_p(t.data_ptr())
-        rc = self._lib.auv_train_shallow(self.device, p(self.X), p(self.y), n, p(perm_d), n_batches, self.batch_size,
-                                         p(self.w), p(self.opt_state), C.byref(self.hp), self.steps_done, p(losses),
-                                         C.c_void_p(st))
+        rc = self._lib.auv_train_cnn(self._kind_id, self.device, p(self.X), p(self.y), n, p(perm_d), n_batches,
+                                     self.batch_size, p(self.w), p(self.opt_state), C.byref(self.hp), self.steps_done,
+                                     p(losses), C.c_void_p(st))
         if rc != 0:
             raise self._api.AuvError(rc, self._lib.auv_cnn_last_error(None).decode())
         self.steps_done += n_batches
@@ -128,7 +140,7 @@ class DeviceTrainer:
             return float("nan")
         from .cnn import LidarCNN
 
-        net = LidarCNN("shallow", self.sync_model().state_dict(), device=self.device)
+        net = LidarCNN(self.kind, self.sync_model().state_dict(), device=self.device)
         pred = net.forward(self.Xv.reshape(-1, 1, 180), "risk")[:, 0]
         net.close()
         # the reference averages the losses of the validation batches (trainer.py:55-69)
