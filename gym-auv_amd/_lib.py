@@ -55,7 +55,7 @@ EXPORTS = (
     "auv_set_scene", "auv_reset", "auv_step", "auv_step_host", "auv_sense",
     "auv_get_buffer", "auv_read_buffer", "auv_dlpack", "auv_sync", "auv_set_option",
     "auv_profile_enable", "auv_cnn_n_weights", "auv_cnn_out_dim", "auv_cnn_create", "auv_cnn_destroy",
-    "auv_cnn_forward", "auv_cnn_last_error", "auv_format_rows",
+    "auv_cnn_forward", "auv_cnn_last_error", "auv_format_rows", "auv_format_rows_device",
     "auv_profile_read", "auv_attach_cnn", "auv_generate_scene", "auv_host_alloc", "auv_host_free",
     "auv_risk_rows", "auv_episode_stats", "auv_episode_stats_static", "auv_train_shallow", "auv_train_cnn", "auv_set_path",
 )
@@ -148,6 +148,8 @@ def load():
     lib.auv_profile_read.argtypes = [vp, dp, C.POINTER(i64)]
     lib.auv_format_rows.restype = i64
     lib.auv_format_rows.argtypes = [vp, vp, i64, i64, vp, i64]
+    lib.auv_format_rows_device.restype = C.c_int
+    lib.auv_format_rows_device.argtypes = [C.c_int, vp, vp, i64, i64, vp, i64, vp, vp, vp]
     lib.auv_cnn_n_weights.restype = C.c_int
     lib.auv_cnn_n_weights.argtypes = [i32]
     lib.auv_cnn_out_dim.restype = C.c_int

@@ -23,6 +23,7 @@
 #include "auv_format.hpp"
 #include "auv_stats.hpp"
 #include "auv_train.hpp"
+#include "auv_format_device.hpp"
 
 using namespace auv;
 
@@ -1228,6 +1229,30 @@ int64_t auv_format_rows(const double* values, const int32_t* row_len, int64_t n_
         pos += got[(size_t)t];
     }
     return pos;
+}
+
+int auv_format_rows_device(int device, const double* values, const int32_t* row_len, int64_t n_rows, int64_t stride,
+                           char* text, int64_t text_cap, int64_t* row_off, int32_t* status, void* stream) {
+    if (!values || !text || !row_off || !status) return AUV_ERR_ARG;
+    if (n_rows < 0 || n_rows > 0x7fffffffLL || stride < 1 || text_cap < 0) return AUV_ERR_ARG;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return AUV_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return AUV_ERR_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(status, 0, 2 * sizeof(int32_t), st) != hipSuccess) return AUV_ERR_DEVICE;
+    FmtArgs a;
+    a.values = values;
+    a.row_len = row_len;
+    a.n_rows = n_rows;
+    a.stride = stride;
+    a.text = text;
+    a.text_cap = text_cap;
+    a.row_off = reinterpret_cast<long long*>(row_off);
+    a.status = status;
+    if (n_rows > 0) hipLaunchKernelGGL(k_fmt_row_bytes, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_fmt_scan, dim3(1), dim3(1024), 0, st, a.row_off, (long long)n_rows);
+    if (n_rows > 0) hipLaunchKernelGGL(k_fmt_write, dim3((unsigned)n_rows), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? AUV_OK : AUV_ERR_DEVICE;
 }
 
 // ---- LiDAR-CNN consumers ----------------------------------------------------

@@ -83,6 +83,10 @@ class DatasetWriter:
         self.rows += n
         return n
 
+    def write_text(self, kind, text):
+        """Append rows already formatted (`DeviceRowFormatter`) to one of the three files."""
+        self._f[kind].write(memoryview(text))
+
     def close(self):
         for f in self._f.values():
             f.close()
@@ -136,6 +140,149 @@ class DatasetLogger:
         tracked = self._tracked & due[:, None]
         return self.writer.write(sim.read("ranges", stream, pinned=True), sim.read("own", stream, pinned=True),
                                  meta, sim.read("risk", stream, pinned=True), tracked)
+
+
+class DeviceRowFormatter:
+    """Text of ragged rows formed on the GPU (`auv_format_rows_device`): the
+    rows leave the device as the bytes that go to the file.  One instance keeps
+    its device text buffer, row offsets and page-locked host buffer between
+    calls (grown when a call needs more)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        self.device = int(device)
+        self._text = self._off = self._status = self._host = None
+        self.host_fallbacks = 0     # blocks that held a value outside the device's range
+
+    def format(self, values, row_len=None, stream=None):
+        """values: contiguous float64 CUDA tensor [n, stride]; row_len: int32 CUDA
+        tensor [n] or None (whole rows).  Launches the formatting on `stream` (a
+        torch stream; default: the current one) and returns a ticket for `fetch`."""
+        import torch
+
+        if not (values.is_cuda and values.dtype == torch.float64 and values.dim() == 2 and values.is_contiguous()):
+            raise ValueError("values must be a contiguous 2-D float64 CUDA tensor")
+        if values.device.index != self.device:
+            raise ValueError(f"values on cuda:{values.device.index}, formatter on cuda:{self.device}")
+        n, stride = values.shape
+        if stride < 1:
+            raise ValueError("rows need at least one column")
+        if row_len is not None and not (row_len.is_cuda and row_len.dtype == torch.int32 and row_len.shape == (n,)
+                                        and row_len.is_contiguous() and row_len.device == values.device):
+            raise ValueError("row_len must be a contiguous int32 CUDA tensor [n] on the values' device")
+        cap = 26 * n * stride + n + 64        # what the widest rows would take
+        dev = values.device
+        if self._text is None or self._text.numel() < cap:
+            self._text = torch.empty(cap, dtype=torch.uint8, device=dev)
+        if self._off is None or self._off.numel() < n + 3:
+            self._off = torch.empty(n + 3, dtype=torch.int64, device=dev)   # row offsets, total, then the status words
+        st = torch.cuda.current_stream(dev) if stream is None else stream
+        off = self._off
+        status_ptr = off.data_ptr() + 8 * (n + 1)
+        rc = self._lib.auv_format_rows_device(self.device, C.c_void_p(values.data_ptr()),
+                                              None if row_len is None else C.c_void_p(row_len.data_ptr()), n, stride,
+                                              C.c_void_p(self._text.data_ptr()), self._text.numel(),
+                                              C.c_void_p(off.data_ptr()), C.c_void_p(status_ptr),
+                                              C.c_void_p(st.cuda_stream))
+        if rc != 0:
+            raise _lib.AuvError(rc, "auv_format_rows_device")
+        return {"values": values, "row_len": row_len, "n": n, "stream": st}
+
+    def tail(self, ticket):
+        """The two words to read back before `fetch`: [bytes in all, status] (device tensor view, int64)."""
+        return self._off[ticket["n"]:ticket["n"] + 2]
+
+    def fetch(self, ticket, tail=None):
+        """The text of a `format` call as a uint8 numpy array (a view of this object's page-locked buffer, valid
+        until the next fetch).  `tail`: the two words of `tail(ticket)` already on the host (saves a round trip
+        when several formatters are read together)."""
+        import torch
+
+        with torch.cuda.stream(ticket["stream"]):
+            if tail is None:
+                tail = self.tail(ticket).cpu()
+            total = int(tail[0])
+            bad, overflow = int(tail[1]) & 0xffffffff, int(tail[1]) >> 32
+            if overflow:
+                raise RuntimeError("auv_format_rows_device: text buffer too small")   # cannot happen: sized for the widest rows
+            if bad:
+                # infinities, NaN or magnitudes outside 1e-36 .. 1e18: the host formatter handles every double
+                self.host_fallbacks += 1
+                rl = None if ticket["row_len"] is None else ticket["row_len"].cpu().numpy()
+                return format_rows(ticket["values"].cpu().numpy(), rl, view=True)
+            if self._host is None or self._host.numel() < total:
+                self._host = torch.empty(max(total, 1 << 20), dtype=torch.uint8, pin_memory=True)
+            self._host[:total].copy_(self._text[:total], non_blocking=True)
+            ticket["stream"].synchronize()
+        return self._host[:total].numpy()
+
+
+def format_rows_device(values, row_len=None):
+    """One-off form of `DeviceRowFormatter`: bytes of the rows of a CUDA tensor."""
+    f = DeviceRowFormatter(values.device.index)
+    return f.fetch(f.format(values, row_len)).tobytes()
+
+
+class DeviceDatasetLogger:
+    """`DatasetLogger` with the rows built and formatted on the GPU: the
+    obstacle lists (`update_tracked`), the choice and compaction of the rows
+    and the "%.18e" text all stay on the device; the host receives the bytes of
+    the three files and writes them (one thread per file).  Same files, byte
+    for byte, as `DatasetLogger` writes from the same simulation.  `stream`:
+    the torch stream the simulation is stepped on (default: the current one)."""
+
+    def __init__(self, sim, writer: DatasetWriter, every: int = 5, refresh_every: int = 25):
+        self.sim, self.writer, self.every, self.refresh_every = sim, writer, int(every), int(refresh_every)
+        self._tracked = None
+        self._buf = {k: sim.tensor(k) for k in ("t_step", "meta", "obst_dist", "ranges", "own", "risk")}
+        dev = self._buf["meta"].device.index
+        self._fmt = {k: DeviceRowFormatter(dev) for k in ("LiDAR", "risk", "metadata")}
+        self._pool = None
+
+    def after_step(self, stream=None):
+        import torch
+
+        b = self._buf
+        st = torch.cuda.current_stream(b["meta"].device) if stream is None else stream
+        with torch.cuda.stream(st):
+            t = b["t_step"]
+            due = (t % self.every) == 0
+            if not bool(due.any()):
+                return 0
+            meta = b["meta"]
+            present = torch.isfinite(b["obst_dist"])
+            fresh = present & (meta[:, :, 1] < float(self.sim.cfg["sensor_range"]))
+            if self._tracked is None:
+                self._tracked = fresh
+            else:
+                rebuild = (t % self.refresh_every) == 0
+                self._tracked = torch.where(rebuild[:, None], fresh, self._tracked & present)
+            trk = self._tracked & due[:, None]
+            idx = trk.any(dim=1).nonzero(as_tuple=False).squeeze(1)
+            n = int(idx.numel())
+            if n == 0:
+                return 0
+            everyone = n == trk.shape[0]
+            pick = (lambda x: x) if everyone else (lambda x: x[idx])
+            trk = pick(trk)
+            cnt = trk.sum(dim=1, dtype=torch.int32)
+            # the tracked obstacles of each sample to the front, id order kept
+            order = torch.argsort((~trk).to(torch.uint8), dim=1, stable=True)
+            risk_c = torch.gather(pick(b["risk"]), 1, order)
+            meta_c = torch.gather(pick(meta), 1, order[:, :, None].expand(-1, -1, 5)).reshape(n, -1)
+            rows = {"LiDAR": (pick(b["ranges"]).reshape(n, -1).contiguous(), None),
+                    "risk": (risk_c.contiguous(), cnt),
+                    "metadata": (torch.cat([pick(b["own"]).reshape(n, 2), meta_c], dim=1), (2 + 5 * cnt).to(torch.int32))}
+            tickets = {k: self._fmt[k].format(v, rl, st) for k, (v, rl) in rows.items()}
+            tails = torch.stack([self._fmt[k].tail(tickets[k]) for k in rows]).cpu()    # one read-back for the three
+            texts = {k: self._fmt[k].fetch(tickets[k], tails[i]) for i, k in enumerate(rows)}
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(3)
+        for job in [self._pool.submit(self.writer.write_text, k, txt) for k, txt in texts.items()]:
+            job.result()
+        self.writer.rows += n
+        return n
 
 
 def save_binary(path, ranges, own, meta, risk, tracked):

@@ -320,6 +320,17 @@ int auv_episode_stats_static(auv_handle h, double* out, int32_t accumulate, void
  * + 1 per row always suffice), AUV_ERR_ARG on a null pointer. */
 int64_t auv_format_rows(const double* values, const int32_t* row_len, int64_t n_rows, int64_t stride,
                         char* out, int64_t out_cap);
+/* The same text formed on the device (the rows leave the GPU as bytes ready for the file; the digits are the
+ * host formatter's arithmetic in 192-bit integers).  All pointers are DEVICE memory on `device`:
+ *   values [n_rows, stride] f64, row_len [n_rows] i32 or NULL (every row holds `stride` values),
+ *   text [text_cap] bytes out (26 per value + 1 per row always suffice),
+ *   row_off [n_rows + 1] i64 out: where each row starts in `text`; row_off[n_rows] = bytes in all,
+ *   status [2] i32 out: [0] values the device does not format (it covers zero and 1e-36 <= |v| < 1e18:
+ *   everything a dataset row holds; infinities, NaN and magnitudes outside are counted, and the caller
+ *   formats that block with auv_format_rows instead), [1] rows that did not fit text_cap (not written).
+ * Asynchronous on `stream`; read status and row_off[n_rows] after synchronising. */
+int auv_format_rows_device(int device, const double* values, const int32_t* row_len, int64_t n_rows, int64_t stride,
+                           char* text, int64_t text_cap, int64_t* row_off, int32_t* status, void* stream);
 
 /* ---- dataset records -> risk (device pointers) -----------------------------
  * The AUV_RISK_REFERENCE index evaluated on n dataset records: per obstacle

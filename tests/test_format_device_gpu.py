@@ -1,0 +1,98 @@
+"""The dataset text formed on the device (`auv_format_rows_device`, `DeviceRowFormatter`,
+`DeviceDatasetLogger`) against the host formatter (itself held to printf's "%.18e" by
+tests/test_dataset_cpu.py) and against Python's own "%.18e": byte for byte."""
+import numpy as np
+import pytest
+import torch
+
+from gym_auv_amd import _lib, params, scenarios
+from gym_auv_amd import dataset as D
+from gym_auv_amd.sim import AuvSim
+
+pytestmark = pytest.mark.gpu
+
+
+def _awkward_values(rng, n):
+    """Doubles across the device's range (1e-36 .. 1e18), both signs, with the cases a decimal conversion gets
+    wrong first: powers of ten and their neighbours, ties, long runs of nines, powers of two, zeros."""
+    mag = 10.0 ** rng.uniform(-36, 18, n)
+    v = mag * rng.choice([-1.0, 1.0], n)
+    special = [0.0, -0.0, 1.0, -1.0, 0.1, 0.5, 1.0 / 3.0, 2.0 / 3.0, 150.0, 149.99999999999997, 3.255,
+               1e-36, 9.999999999999999e17, 1e17, 123456789012345678.0, 0.30000000000000004, 5e-1, 2.5, 0.125,
+               9.9999999999999995e-8, 1.0000000000000002, 0.9999999999999999, 999999999999999.9, 4.35, 0.045]
+    special += [10.0 ** k for k in range(-36, 18)]
+    special += [np.nextafter(10.0 ** k, 0.0) for k in range(-35, 18)] + [np.nextafter(10.0 ** k, np.inf) for k in range(-36, 17)]
+    special += [2.0 ** k for k in range(-119, 59, 3)] + [-(2.0 ** k) for k in range(-100, 50, 7)]
+    special += [float(np.float64(k) + 0.5) for k in range(0, 40)]                     # exact ties at fewer digits
+    special += [float(int("9" * d)) for d in range(1, 18)] + [float(int("9" * d) + 1) for d in range(1, 18)]
+    v[:len(special)] = special
+    assert all(x == 0.0 or 1e-36 <= abs(x) < 1e18 for x in special)
+    return v
+
+
+def test_device_text_equals_host_text_and_python():
+    rng = np.random.default_rng(11)
+    stride = 301
+    vals = _awkward_values(rng, 700 * stride).reshape(700, stride)
+    row_len = rng.integers(0, stride + 1, 700).astype(np.int32)
+    row_len[:3] = [stride, 0, 1]
+    dv, dl = torch.from_numpy(vals).cuda(), torch.from_numpy(row_len).cuda()
+    f = D.DeviceRowFormatter(0)
+    t = f.format(dv, dl)
+    got = bytes(f.fetch(t))
+    assert f.host_fallbacks == 0
+    assert got == D.format_rows(vals, row_len)
+    lines = got.split(b"\n")
+    assert lines[-1] == b"" and len(lines) == 701
+    for i in (0, 1, 2, 50, 699):     # Python's own conversion, independently of both formatters
+        assert lines[i] == " ".join("%.18e" % x for x in vals[i, :row_len[i]]).encode()
+    # row offsets: where each line starts
+    off = f._off[:701].cpu().numpy()
+    starts = np.concatenate([[0], np.cumsum([len(x) + 1 for x in lines[:-1]])])
+    assert np.array_equal(off, starts)
+    # whole rows (no row_len), a shape that leaves threads of the last chunk idle
+    t = f.format(dv[:, :257].contiguous())
+    assert bytes(f.fetch(t)) == D.format_rows(vals[:, :257])
+    assert D.format_rows_device(dv[:5].contiguous()) == D.format_rows(vals[:5])
+
+
+def test_values_outside_the_devices_range_take_the_host_formatter():
+    vals = np.array([[1.0, np.inf, 2.0], [1e300, -1e-300, 5e-324], [np.nan, 1e18, 9.9e-37]])
+    f = D.DeviceRowFormatter(0)
+    t = f.format(torch.from_numpy(vals).cuda())
+    tail = f.tail(t).cpu()
+    assert int(tail[1]) == 7                      # everything but 1.0 and 2.0 is counted
+    assert bytes(f.fetch(t)) == D.format_rows(vals) and f.host_fallbacks == 1
+    with pytest.raises(ValueError):
+        f.format(torch.zeros(3, 3, device="cuda"))            # float32
+    with pytest.raises(ValueError):
+        f.format(torch.zeros(3, 3, dtype=torch.float64, device="cuda"), torch.zeros(2, dtype=torch.int32, device="cuda"))
+
+
+def test_device_logger_writes_the_host_loggers_files(tmp_path):
+    """Both loggers follow the same simulation (episodes restarting and scenes regenerated on the way, so the envs
+    drift apart and the obstacle lists are rebuilt at different steps): the three files must be equal byte for byte."""
+    V = 300
+    cfg = params.make_config(V, 8, 8, 5, max_steps=60)
+    sim = AuvSim(cfg)
+    sim.generate_scene(7, scenarios.REFERENCE_LIKE)
+    sim.set_option(_lib.OPT_AUTO_RESET, 1)
+    sim.set_option(_lib.OPT_REGENERATE, 1)
+    sim.reset(None)
+    wh, wd = D.DatasetWriter(str(tmp_path / "host")), D.DatasetWriter(str(tmp_path / "dev"))
+    host, dev = D.DatasetLogger(sim, wh), D.DeviceDatasetLogger(sim, wd)
+    rng = np.random.default_rng(3)
+    act = np.zeros((2, V))
+    for k in range(130):
+        if k % 10 == 0:
+            act[0], act[1] = rng.uniform(0.6, 1.0, V), rng.uniform(-0.3, 0.3, V)
+        sim.step_host(act)
+        assert host.after_step() == dev.after_step()
+    wh.close()
+    wd.close()
+    assert wh.rows == wd.rows > 3000
+    for kind in ("LiDAR", "risk", "metadata"):
+        a, b = open(wh.paths[kind], "rb").read(), open(wd.paths[kind], "rb").read()
+        assert a == b and len(a) > 0, kind
+    assert sum(f.host_fallbacks for f in dev._fmt.values()) == 0
+    sim.close()
