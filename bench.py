@@ -406,24 +406,34 @@ def main():
 
         from gym_auv_amd import dataset as D
 
-        tmp = tempfile.mkdtemp(prefix="auv_rows_")
-        try:
-            sim.reset(scene["init_state"], stream=stream)
-            w = D.DatasetWriter(tmp)
-            lg = D.DatasetLogger(sim, w)
-            t0 = time.perf_counter()
-            for k in range(25):
-                sim.step_device(ptrs[k % n_act], stream=stream)
-                lg.after_step(stream)
-            dt_rows = time.perf_counter() - t0
-            w.close()
-            size = sum(os.path.getsize(pth) for pth in w.paths.values())
-            dataset_rate = {"rows_per_s": w.rows / dt_rows, "rows": w.rows, "seconds": dt_rows,
-                            "text_MB": size / 1e6,
-                            "what": "25 steps, every env logged every 5th step of its episode through DatasetLogger "
-                                    f"(page-locked reads, native %.18e formatter): {R} ranges + risk + metadata per row"}
-        finally:
-            shutil.rmtree(tmp, ignore_errors=True)
+        def regenerate(logger_cls, passes):
+            """rows/s of the last of `passes` identical runs (the first one allocates the staging buffers)"""
+            for _ in range(passes):
+                tmp = tempfile.mkdtemp(prefix="auv_rows_")
+                try:
+                    sim.reset(scene["init_state"], stream=stream)
+                    w = D.DatasetWriter(tmp)
+                    lg = logger_cls(sim, w)
+                    t0 = time.perf_counter()
+                    for k in range(25):
+                        sim.step_device(ptrs[k % n_act], stream=stream)
+                        lg.after_step(stream)
+                    dt_rows = time.perf_counter() - t0
+                    w.close()
+                    size = sum(os.path.getsize(pth) for pth in w.paths.values())
+                finally:
+                    shutil.rmtree(tmp, ignore_errors=True)
+            return w.rows, dt_rows, size
+
+        rows_d, dt_d, size = regenerate(D.DeviceDatasetLogger, 2)
+        rows_h, dt_h, _ = regenerate(D.DatasetLogger, 1)
+        dataset_rate = {"rows_per_s": rows_d / dt_d, "rows": rows_d, "seconds": dt_d, "text_MB": size / 1e6,
+                        "what": "25 steps, every env logged every 5th step of its episode through DeviceDatasetLogger "
+                                "(obstacle lists, row compaction and the %.18e text on the GPU; the host writes the "
+                                f"bytes): {R} ranges + risk + metadata per row",
+                        "host_logger_rows_per_s": rows_h / dt_h,
+                        "host_logger": "the same rows through DatasetLogger (page-locked reads, native formatter on "
+                                       "the host threads); same files byte for byte"}
 
     t = torch.tensor(times, device=dev, dtype=torch.float64)
     auv_dist.all_reduce(t, op=dist.ReduceOp.MAX)   # every repeat: the slowest rank

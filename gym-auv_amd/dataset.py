@@ -54,13 +54,49 @@ def format_rows(values: np.ndarray, row_len=None, view: bool = False):
 
 
 class DatasetWriter:
-    """Appends row-aligned samples to LiDAR_/risk_/metadata_<name>.csv."""
+    """Appends row-aligned samples to LiDAR_/risk_/metadata_<name>.csv.  Text
+    goes out through positional writes; a large block is split over a few
+    threads (the copy into the page cache is what a logged step of a large
+    batch waits for)."""
+
+    CHUNK = 8 << 20     # bytes per positional write of a split block
+    THREADS = 8
 
     def __init__(self, directory: str, name: str = "MovingObstaclesNoRules"):
         os.makedirs(directory, exist_ok=True)
         self.paths = {k: os.path.join(directory, f"{k}_{name}.csv") for k in ("LiDAR", "risk", "metadata")}
-        self._f = {k: open(p, "ab") for k, p in self.paths.items()}
+        self._fd = {k: os.open(p, os.O_WRONLY | os.O_CREAT, 0o644) for k, p in self.paths.items()}
+        self._end = {k: os.fstat(fd).st_size for k, fd in self._fd.items()}      # append behind what is there
+        self._pool = None
         self.rows = 0
+
+    @staticmethod
+    def _put(fd, view, at):
+        while len(view):
+            n = os.pwrite(fd, view, at)
+            view, at = view[n:], at + n
+
+    def write_text(self, kind, text):
+        """Append rows already formatted (bytes, or a uint8 array) to one of the three files."""
+        self.write_texts({kind: text})
+
+    def write_texts(self, texts):
+        """Append a block of formatted rows to each named file; returns when all of it is written."""
+        jobs = []
+        for kind, text in texts.items():
+            view = memoryview(text).cast("B")
+            at, fd = self._end[kind], self._fd[kind]
+            self._end[kind] += len(view)
+            for o in range(0, len(view), self.CHUNK):
+                jobs.append((fd, view[o:o + self.CHUNK], at + o))
+        if len(jobs) == 1:
+            self._put(*jobs[0])
+        elif jobs:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(self.THREADS)
+            for j in [self._pool.submit(self._put, *job) for job in jobs]:
+                j.result()
 
     def write(self, ranges, own, meta, risk, tracked):
         """ranges [n,R], own [n,2], meta [n,O,5], risk [n,O], tracked bool [n,O].
@@ -77,19 +113,18 @@ class DatasetWriter:
         order = np.argsort(~tracked, axis=1, kind="stable")
         risk_c = np.take_along_axis(risk, order, axis=1)
         meta_c = np.take_along_axis(meta, order[:, :, None], axis=1).reshape(n, O * 5)
-        self._f["LiDAR"].write(format_rows(ranges, view=True))
-        self._f["risk"].write(format_rows(risk_c, cnt, view=True))
-        self._f["metadata"].write(format_rows(np.concatenate([own, meta_c], axis=1), 2 + 5 * cnt, view=True))
+        self.write_texts({"LiDAR": format_rows(ranges, view=True), "risk": format_rows(risk_c, cnt, view=True),
+                          "metadata": format_rows(np.concatenate([own, meta_c], axis=1), 2 + 5 * cnt, view=True)})
         self.rows += n
         return n
 
-    def write_text(self, kind, text):
-        """Append rows already formatted (`DeviceRowFormatter`) to one of the three files."""
-        self._f[kind].write(memoryview(text))
-
     def close(self):
-        for f in self._f.values():
-            f.close()
+        for fd in self._fd.values():
+            os.close(fd)
+        self._fd = {}
+        if self._pool is not None:
+            self._pool.shutdown()
+            self._pool = None
 
     def __enter__(self):
         return self
@@ -227,7 +262,7 @@ class DeviceDatasetLogger:
     """`DatasetLogger` with the rows built and formatted on the GPU: the
     obstacle lists (`update_tracked`), the choice and compaction of the rows
     and the "%.18e" text all stay on the device; the host receives the bytes of
-    the three files and writes them (one thread per file).  Same files, byte
+    the three files and writes them.  Same files, byte
     for byte, as `DatasetLogger` writes from the same simulation.  `stream`:
     the torch stream the simulation is stepped on (default: the current one)."""
 
@@ -237,7 +272,6 @@ class DeviceDatasetLogger:
         self._buf = {k: sim.tensor(k) for k in ("t_step", "meta", "obst_dist", "ranges", "own", "risk")}
         dev = self._buf["meta"].device.index
         self._fmt = {k: DeviceRowFormatter(dev) for k in ("LiDAR", "risk", "metadata")}
-        self._pool = None
 
     def after_step(self, stream=None):
         import torch
@@ -276,11 +310,7 @@ class DeviceDatasetLogger:
             tickets = {k: self._fmt[k].format(v, rl, st) for k, (v, rl) in rows.items()}
             tails = torch.stack([self._fmt[k].tail(tickets[k]) for k in rows]).cpu()    # one read-back for the three
             texts = {k: self._fmt[k].fetch(tickets[k], tails[i]) for i, k in enumerate(rows)}
-        if self._pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(3)
-        for job in [self._pool.submit(self.writer.write_text, k, txt) for k, txt in texts.items()]:
-            job.result()
+        self.writer.write_texts(texts)
         self.writer.rows += n
         return n
 

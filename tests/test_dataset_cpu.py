@@ -169,3 +169,22 @@ def test_shipped_rows_follow_the_listing_rule():
             kept_max = max(kept_max, rec[:, 1].max())
         prev = key
     assert changed_max < 150.0 < kept_max
+
+
+def test_writer_appends_behind_existing_rows_and_splits_large_blocks(tmp_path):
+    """A reopened writer continues the files; a block larger than the writer's chunk goes out in pieces
+    (positional writes from several threads) and lands in order."""
+    from gym_auv_amd import dataset as D
+
+    rng = np.random.default_rng(0)
+    blocks = [rng.uniform(-5, 150, (40, 7)) for _ in range(3)]
+    for i, b in enumerate(blocks):
+        w = D.DatasetWriter(str(tmp_path))
+        if i == 2:
+            w.CHUNK = 1000          # 40 rows of 7 numbers are ~7 KB: eight pieces
+        w.write_text("LiDAR", D.format_rows(b))
+        w.write_texts({"risk": D.format_rows(b[:, :2]), "metadata": D.format_rows(b[:, :3], view=True)})
+        w.close()
+    assert open(w.paths["LiDAR"], "rb").read() == b"".join(D.format_rows(b) for b in blocks)
+    assert np.array_equal(np.loadtxt(w.paths["risk"]), np.concatenate(blocks)[:, :2])
+    assert np.array_equal(np.loadtxt(w.paths["metadata"]), np.concatenate(blocks)[:, :3])
