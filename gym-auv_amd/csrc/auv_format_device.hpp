@@ -151,13 +151,20 @@ struct FmtArgs {
     int32_t* status;     // [0] values outside the device's range, [1] rows that did not fit text_cap
 };
 
+// numbers in use in a row, held to what the row can hold
+__device__ __forceinline__ long long fmt_row_len(const FmtArgs& a, long long row) {
+    if (!a.row_len) return a.stride;
+    const long long n = a.row_len[row];
+    return n < 0 ? 0 : (n > a.stride ? a.stride : n);
+}
+
 // bytes of every row: a wave per row counts the signs (a number is 24 characters, its sign if negative, and the
 // blank or newline behind it) and the values the device cannot format
 __global__ __launch_bounds__(256) void k_fmt_row_bytes(FmtArgs a) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= a.n_rows) return;
-    const long long len = a.row_len ? a.row_len[row] : a.stride;
+    const long long len = fmt_row_len(a, row);
     const double* v = a.values + row * a.stride;
     int negs = 0, bad = 0;
     for (long long j = lane; j < len; j += 64) {
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(1024) void k_fmt_scan(long long* row_off, long long
 __global__ __launch_bounds__(256) void k_fmt_write(FmtArgs a) {
     __shared__ int wave_negs[4];
     const long long row = blockIdx.x;
-    const long long len = a.row_len ? a.row_len[row] : a.stride;
+    const long long len = fmt_row_len(a, row);
     const long long start = a.row_off[row], end = a.row_off[row + 1];
     if (end > a.text_cap) {
         if (threadIdx.x == 0) atomicAdd(&a.status[1], 1);

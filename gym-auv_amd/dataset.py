@@ -266,12 +266,37 @@ class DeviceDatasetLogger:
     for byte, as `DatasetLogger` writes from the same simulation.  `stream`:
     the torch stream the simulation is stepped on (default: the current one)."""
 
-    def __init__(self, sim, writer: DatasetWriter, every: int = 5, refresh_every: int = 25):
+    def __init__(self, sim, writer: DatasetWriter | None, every: int = 5, refresh_every: int = 25,
+                 collect: str | None = None):
+        """writer None: no files.  collect "max" / "sum" / "mean": every logged row is also kept on the device
+        as a training sample, the scan as the network sees it and the label `calculate_total_risk` would form
+        from the row's risk record; `samples()` returns what `load_lidar_dataset(..., mode=collect)` would
+        read back from the files, without the files."""
         self.sim, self.writer, self.every, self.refresh_every = sim, writer, int(every), int(refresh_every)
+        if writer is None and collect is None:
+            raise ValueError("nothing to do: no writer and no samples to collect")
+        if collect not in (None, "max", "sum", "mean"):
+            raise ValueError("collect must be None, 'max', 'sum' or 'mean'")
+        self.collect = collect
         self._tracked = None
-        self._buf = {k: sim.tensor(k) for k in ("t_step", "meta", "obst_dist", "ranges", "own", "risk")}
+        names = ("t_step", "meta", "obst_dist", "ranges", "own", "risk") + (("perception",) if collect else ())
+        self._buf = {k: sim.tensor(k) for k in names}
         dev = self._buf["meta"].device.index
         self._fmt = {k: DeviceRowFormatter(dev) for k in ("LiDAR", "risk", "metadata")}
+        self._X, self._y = [], []
+        self.rows = 0
+
+    def samples(self):
+        """(X float32 [n,1,R], y float32 [n,1]) of the rows logged so far, on the device, in file order."""
+        import torch
+
+        if not self.collect:
+            raise ValueError("this logger was not asked to collect samples")
+        if not self._X:
+            R = self._buf["perception"].shape[-1]
+            dev = self._buf["perception"].device
+            return torch.empty((0, 1, R), dtype=torch.float32, device=dev), torch.empty((0, 1), dtype=torch.float32, device=dev)
+        return torch.cat(self._X), torch.cat(self._y)
 
     def after_step(self, stream=None):
         import torch
@@ -303,15 +328,31 @@ class DeviceDatasetLogger:
             # the tracked obstacles of each sample to the front, id order kept
             order = torch.argsort((~trk).to(torch.uint8), dim=1, stable=True)
             risk_c = torch.gather(pick(b["risk"]), 1, order)
-            meta_c = torch.gather(pick(meta), 1, order[:, :, None].expand(-1, -1, 5)).reshape(n, -1)
-            rows = {"LiDAR": (pick(b["ranges"]).reshape(n, -1).contiguous(), None),
-                    "risk": (risk_c.contiguous(), cnt),
-                    "metadata": (torch.cat([pick(b["own"]).reshape(n, 2), meta_c], dim=1), (2 + 5 * cnt).to(torch.int32))}
-            tickets = {k: self._fmt[k].format(v, rl, st) for k, (v, rl) in rows.items()}
-            tails = torch.stack([self._fmt[k].tail(tickets[k]) for k in rows]).cpu()    # one read-back for the three
-            texts = {k: self._fmt[k].fetch(tickets[k], tails[i]) for i, k in enumerate(rows)}
-        self.writer.write_texts(texts)
-        self.writer.rows += n
+            if self.collect:
+                # the label of utils/dataloader.py:104-120: over at most 8 columns of the row's risk record
+                k = min(8, risk_c.shape[1])
+                head = risk_c[:, :k]
+                listed = torch.arange(k, device=head.device)[None, :] < cnt[:, None]
+                if self.collect == "max":
+                    y = torch.where(listed, head, head.new_full((), -float("inf"))).max(dim=1).values
+                else:
+                    y = torch.where(listed, head, head.new_zeros(())).sum(dim=1)
+                    if self.collect == "mean":
+                        y = y / torch.clamp(cnt, max=k).to(y.dtype)
+                self._X.append(pick(b["perception"]).reshape(n, 1, -1).clone())
+                self._y.append(y.to(torch.float32)[:, None])
+            if self.writer is not None:
+                meta_c = torch.gather(pick(meta), 1, order[:, :, None].expand(-1, -1, 5)).reshape(n, -1)
+                rows = {"LiDAR": (pick(b["ranges"]).reshape(n, -1).contiguous(), None),
+                        "risk": (risk_c.contiguous(), cnt),
+                        "metadata": (torch.cat([pick(b["own"]).reshape(n, 2), meta_c], dim=1), (2 + 5 * cnt).to(torch.int32))}
+                tickets = {k: self._fmt[k].format(v, rl, st) for k, (v, rl) in rows.items()}
+                tails = torch.stack([self._fmt[k].tail(tickets[k]) for k in rows]).cpu()    # one read-back for the three
+                texts = {k: self._fmt[k].fetch(tickets[k], tails[i]) for i, k in enumerate(rows)}
+        if self.writer is not None:
+            self.writer.write_texts(texts)
+            self.writer.rows += n
+        self.rows += n
         return n
 
 

@@ -110,7 +110,13 @@ class DeviceTrainer:
         if perm is None:
             perm = torch.randperm(n, generator=self._gen)
         n_batches = n // self.batch_size
-        perm_d = torch.as_tensor(perm, dtype=torch.int32)[:n_batches * self.batch_size].contiguous().to(self.X.device)
+        perm = torch.as_tensor(perm)
+        if perm.numel() < n_batches * self.batch_size:
+            raise ValueError(f"perm holds {perm.numel()} rows; {n_batches} batches of {self.batch_size} need {n_batches * self.batch_size}")
+        perm = perm[:n_batches * self.batch_size]
+        if n_batches and (int(perm.min()) < 0 or int(perm.max()) >= n):     # the kernel indexes X and y with it unchecked
+            raise ValueError(f"perm must hold row numbers in 0..{n - 1}")
+        perm_d = perm.to(torch.int32).contiguous().to(self.X.device)
         losses = torch.empty(n_batches, dtype=torch.float32, device=self.X.device)
         st = torch.cuda.current_stream(self.X.device).cuda_stream
         p = lambda t: C.c_void_p(t.data_ptr())

@@ -80,7 +80,8 @@ def test_device_logger_writes_the_host_loggers_files(tmp_path):
     sim.set_option(_lib.OPT_REGENERATE, 1)
     sim.reset(None)
     wh, wd = D.DatasetWriter(str(tmp_path / "host")), D.DatasetWriter(str(tmp_path / "dev"))
-    host, dev = D.DatasetLogger(sim, wh), D.DeviceDatasetLogger(sim, wd)
+    host, dev = D.DatasetLogger(sim, wh), D.DeviceDatasetLogger(sim, wd, collect="max")
+    only_samples = {m: D.DeviceDatasetLogger(sim, None, collect=m) for m in ("sum", "mean")}
     rng = np.random.default_rng(3)
     act = np.zeros((2, V))
     for k in range(130):
@@ -88,6 +89,8 @@ def test_device_logger_writes_the_host_loggers_files(tmp_path):
             act[0], act[1] = rng.uniform(0.6, 1.0, V), rng.uniform(-0.3, 0.3, V)
         sim.step_host(act)
         assert host.after_step() == dev.after_step()
+        for lg in only_samples.values():
+            lg.after_step()
     wh.close()
     wd.close()
     assert wh.rows == wd.rows > 3000
@@ -95,4 +98,21 @@ def test_device_logger_writes_the_host_loggers_files(tmp_path):
         a, b = open(wh.paths[kind], "rb").read(), open(wd.paths[kind], "rb").read()
         assert a == b and len(a) > 0, kind
     assert sum(f.host_fallbacks for f in dev._fmt.values()) == 0
+    # the samples kept on the device are what the reference's loader reads back from the files
+    # (utils/dataloader.py:44-120: X = 1 - X/150 as float32 with a channel axis, y = the row's largest risk)
+    X, y = dev.samples()
+    assert X.shape == (wd.rows, 1, 180) and y.shape == (wd.rows, 1) and X.dtype == y.dtype == torch.float32
+    data = D.load_lidar_dataset(wd.paths["LiDAR"], wd.paths["risk"], mode="max")
+    Xf = np.concatenate([data[k][0] for k in ("train", "val", "test")])
+    yf = np.concatenate([data[k][1] for k in ("train", "val", "test")])
+    assert np.array_equal(X.cpu().numpy(), Xf) and np.array_equal(y.cpu().numpy(), yf)
+    for mode, lg in only_samples.items():        # summation orders differ from numpy's: a float32 ulp at most
+        Xm, ym = lg.samples()
+        want = D.calculate_total_risk(wd.paths["risk"], mode).astype(np.float32)
+        assert torch.equal(Xm, X) and np.abs(ym[:, 0].cpu().numpy() - want).max() <= 1e-6, mode
+    with pytest.raises(ValueError):
+        D.DeviceDatasetLogger(sim, None)
+    with pytest.raises(ValueError):
+        host_only = D.DeviceDatasetLogger(sim, wd)
+        host_only.samples()
     sim.close()

@@ -76,6 +76,11 @@ def test_device_trainer_refuses_other_models():
         T.DeviceTrainer(torch.nn.Linear(180, 1), 1, 1e-3, *_data(16, 0))
     with pytest.raises(ValueError):
         T.DeviceTrainer(MODELS["deep"](channels=(2, 2, 2, 2)), 1, 1e-3, *_data(16, 0))
+    t = T.DeviceTrainer(MODELS["deep2"](), 1, 1e-3, *_data(32, 0))
+    with pytest.raises(ValueError):
+        t.train_epoch(torch.arange(32) + 1)        # row 32 does not exist
+    with pytest.raises(ValueError):
+        t.train_epoch(torch.arange(20))            # two batches of 16 need 32 row numbers
 
 
 @pytest.mark.parametrize("kind,col,epochs,lr", [("shallow", 0, 12, 2e-3), ("deep2", 1, 12, 2e-3), ("deep", 2, 12, 1e-3)])
