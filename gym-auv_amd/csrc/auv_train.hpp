@@ -232,10 +232,11 @@ __host__ __device__ constexpr size_t train_net_lds_bytes(int kind) {
             (size_t)kTrainBatchMax * (train_act_floats(kind) + train_dpre_floats(kind) + train_dout_floats(kind) + 1)) * 4 +
            (size_t)kTrainBatchMax * train_mask_bytes(kind);
 }
-// lanes that share one parameter's gradient sum: a power of two up to 64, as many as keep one pass over the workgroup
-__host__ __device__ constexpr int train_group(int n_items) {
+// lanes that share one parameter's gradient sum: a power of two up to 64, as many as keep one pass over the
+// workgroup's nt threads
+__host__ __device__ constexpr int train_group(int n_items, int nt) {
     int g = 1;
-    while (g < 64 && n_items * g * 2 <= kTrainNetThreads) g *= 2;
+    while (g < 64 && n_items * g * 2 <= nt) g *= 2;
     return g;
 }
 
@@ -250,14 +251,14 @@ struct TrainLds {
 };
 
 // forward of layer l for the B samples of the batch; one thread per output element
-template <int KIND, int l>
+template <int KIND, int l, int NT>
 __device__ __forceinline__ void train_forward_layer(const TrainLds& m, int B, int tid) {
     constexpr TrainLayer D = train_layer(KIND, l);
     constexpr int Lc = tl_conv_len(D), Lo = tl_out_len(D), n_out = tl_n_out(D), A = train_act_floats(KIND);
     constexpr int in_off = l == 0 ? 0 : train_act_off(KIND, l - 1), out_off = train_act_off(KIND, l);
     constexpr int w_off = train_w_off(KIND, l), b_off = w_off + tl_n_weights(D);
     static_assert(D.pad <= D.L && (Lc - 1) * D.stride + D.K - 1 - D.pad < 2 * D.L, "one wrap at most");
-    for (int idx = tid; idx < B * n_out; idx += kTrainNetThreads) {
+    for (int idx = tid; idx < B * n_out; idx += NT) {
         const int s = idx / n_out, el = idx - s * n_out;
         const int co = el / Lo, lo = el - co * Lo;
         const float* in = m.act + s * A + in_off;
@@ -289,17 +290,17 @@ __device__ __forceinline__ void train_forward_layer(const TrainLds& m, int B, in
     }
 }
 
-template <int KIND, int l>
+template <int KIND, int l, int NT>
 __device__ __forceinline__ void train_forward_from(const TrainLds& m, int B, int tid) {
-    train_forward_layer<KIND, l>(m, B, tid);
+    train_forward_layer<KIND, l, NT>(m, B, tid);
     __syncthreads();
-    if constexpr (l + 1 < train_n_layers(KIND)) train_forward_from<KIND, l + 1>(m, B, tid);
+    if constexpr (l + 1 < train_n_layers(KIND)) train_forward_from<KIND, l + 1, NT>(m, B, tid);
 }
 
 // backward of layer l: dout holds the gradient with respect to the layer's
 // output on entry, with respect to its input on return (layer 0: untouched);
 // the gradients of the layer's parameters go to grad[]
-template <int KIND, int l>
+template <int KIND, int l, int NT>
 __device__ __forceinline__ void train_backward_layer(const TrainLds& m, int B, int tid) {
     constexpr TrainLayer D = train_layer(KIND, l);
     constexpr int Lc = tl_conv_len(D), Lo = tl_out_len(D), n_in = tl_n_in(D), A = train_act_floats(KIND);
@@ -307,7 +308,7 @@ __device__ __forceinline__ void train_backward_layer(const TrainLds& m, int B, i
     constexpr int w_off = train_w_off(KIND, l), b_off = w_off + tl_n_weights(D);
     constexpr int DP = train_dpre_floats(KIND), DO = train_dout_floats(KIND);
     // through the pooling and the ReLU: only the element a pooled output came from, and only if it was positive
-    for (int idx = tid; idx < B * D.Cout * Lc; idx += kTrainNetThreads) {
+    for (int idx = tid; idx < B * D.Cout * Lc; idx += NT) {
         const int s = idx / (D.Cout * Lc), r = idx - s * (D.Cout * Lc);
         const int co = r / Lc, pos = r - co * Lc;
         const int o = co * Lo + (D.pool ? pos >> 1 : pos);
@@ -318,8 +319,8 @@ __device__ __forceinline__ void train_backward_layer(const TrainLds& m, int B, i
     }
     __syncthreads();
     // parameters: one item per weight, and per bias; G lanes share an item's sum over samples and positions
-    constexpr int per_co = D.Cin * D.K + 1, n_items = D.Cout * per_co, G = train_group(n_items);
-    for (int base = 0; base < n_items * G; base += kTrainNetThreads) {  // the same trip count for every thread
+    constexpr int per_co = D.Cin * D.K + 1, n_items = D.Cout * per_co, G = train_group(n_items, NT);
+    for (int base = 0; base < n_items * G; base += NT) {  // the same trip count for every thread
         const int idx = base + tid, item = idx / G, g = idx - item * G;
         const bool on = item < n_items;
         const int co = on ? item / per_co : 0, q = on ? item - co * per_co : 0;
@@ -345,7 +346,7 @@ __device__ __forceinline__ void train_backward_layer(const TrainLds& m, int B, i
     // input of the layer = output of the one before
     if constexpr (l > 0) {
         static_assert(D.stride == 1 && Lc == D.L, "the inner layers keep their length");
-        for (int idx = tid; idx < B * n_in; idx += kTrainNetThreads) {
+        for (int idx = tid; idx < B * n_in; idx += NT) {
             const int s = idx / n_in, r = idx - s * n_in;
             const int ci = r / D.L, p = r - ci * D.L;
             float acc = 0.f;
@@ -366,10 +367,10 @@ __device__ __forceinline__ void train_backward_layer(const TrainLds& m, int B, i
     __syncthreads();
 }
 
-template <int KIND, int l>
+template <int KIND, int l, int NT>
 __device__ __forceinline__ void train_backward_from(const TrainLds& m, int B, int tid) {
-    train_backward_layer<KIND, l>(m, B, tid);
-    if constexpr (l > 0) train_backward_from<KIND, l - 1>(m, B, tid);
+    train_backward_layer<KIND, l, NT>(m, B, tid);
+    if constexpr (l > 0) train_backward_from<KIND, l - 1, NT>(m, B, tid);
 }
 
 // One workgroup of 1,024 threads; parameters, the batch's activations and
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(kTrainNetThreads) void k_train_net(TrainArgs a) {
             m.act[s * A + j] = a.X[(long long)a.perm[b * B + s] * kCnnLen + j];
         }
         __syncthreads();
-        train_forward_from<KIND, 0>(m, B, tid);
+        train_forward_from<KIND, 0, kTrainNetThreads>(m, B, tid);
         // loss = mean over the batch of (yhat - y)^2
         if (tid < B) {
             const float err = m.act[tid * A + train_act_off(KIND, NL - 1)] - a.y[a.perm[b * B + tid]];
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(kTrainNetThreads) void k_train_net(TrainArgs a) {
             m.dout[tid * train_dout_floats(KIND)] = 2.f * err / (float)B;
         }
         __syncthreads();
-        train_backward_from<KIND, NL - 1>(m, B, tid);
+        train_backward_from<KIND, NL - 1, kTrainNetThreads>(m, B, tid);
         pow1 *= a.beta1;
         pow2 *= a.beta2;
 #pragma unroll
@@ -463,6 +464,88 @@ __global__ __launch_bounds__(kTrainNetThreads) void k_train_net(TrainArgs a) {
             a.opt[p] = mom[j];
             a.opt[NP + p] = var[j];
         }
+    }
+}
+
+// ---- the same step with a workgroup per sample ------------------------------
+// For the largest network one CU is the limit of k_train_net (its batch is
+// ~1.2 M multiply-adds on 64 lanes per cycle).  Here a batch is two launches:
+// k_train_sample, one workgroup per sample of the batch (forward, loss,
+// backward; the sample's parameter gradients go to `gsample`), then
+// k_train_update (gradient = the samples' in order, optimizer step; parameters
+// and optimizer state stay in global memory between launches).  Batches are
+// still sequential: the host enqueues the 2 x n_batches launches of an epoch.
+struct TrainSplitArgs {
+    TrainArgs t;
+    long long batch_index;  // which batch of perm / batch_loss
+    float* gsample;         // [16][params padded] per-sample gradients
+    float* err2;            // [16] squared errors of the batch
+    double pow1, pow2;      // beta1^step, beta2^step of THIS step (step counted from 1)
+};
+
+constexpr int kTrainSampleThreads = 1024;
+__host__ __device__ constexpr size_t train_sample_lds_bytes(int kind) {
+    return ((size_t)2 * train_params_padded(kind) + train_act_floats(kind) + train_dpre_floats(kind) +
+            train_dout_floats(kind) + 1) * 4 + train_mask_bytes(kind);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kTrainSampleThreads) void k_train_sample(TrainSplitArgs a) {
+    extern __shared__ __align__(16) unsigned char train_lds[];
+    constexpr int NP = cnn_n_weights(KIND), NPP = train_params_padded(KIND), NL = train_n_layers(KIND);
+    constexpr int NT = kTrainSampleThreads;
+    TrainLds m;
+    m.w = reinterpret_cast<float*>(train_lds);
+    m.grad = m.w + NPP;
+    m.act = m.grad + NPP;
+    m.dpre = m.act + train_act_floats(KIND);
+    m.dout = m.dpre + train_dpre_floats(KIND);
+    m.err2 = m.dout + train_dout_floats(KIND);
+    m.mask = reinterpret_cast<unsigned char*>(m.err2 + 1);
+    const int tid = threadIdx.x, s = blockIdx.x, B = a.t.batch;
+    const long long row = a.t.perm[a.batch_index * B + s];
+    for (int p = tid; p < NP; p += NT) m.w[p] = a.t.w[p];
+    for (int j = tid; j < kCnnLen; j += NT) m.act[j] = a.t.X[row * kCnnLen + j];
+    __syncthreads();
+    train_forward_from<KIND, 0, NT>(m, 1, tid);
+    if (tid == 0) {
+        const float err = m.act[train_act_off(KIND, NL - 1)] - a.t.y[row];
+        a.err2[s] = err * err;
+        m.dout[0] = 2.f * err / (float)B;
+    }
+    __syncthreads();
+    train_backward_from<KIND, NL - 1, NT>(m, 1, tid);
+    for (int p = tid; p < NP; p += NT) a.gsample[(size_t)s * NPP + p] = m.grad[p];
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_train_update(TrainSplitArgs a) {
+    constexpr int NP = cnn_n_weights(KIND), NPP = train_params_padded(KIND);
+    const int p = blockIdx.x * 256 + threadIdx.x, B = a.t.batch;
+    if (p < NP) {
+        float grad = 0.f;
+        for (int q = 0; q < B; ++q) grad += a.gsample[(size_t)q * NPP + p];
+        float w = a.t.w[p], mom = a.t.opt[p], var = a.t.opt[NP + p];
+        if (a.t.optimizer == 0) {
+            w = w * (float)(1.0 - a.t.lr * a.t.weight_decay);
+            mom = mom + (grad - mom) * (float)(1.0 - a.t.beta1);
+            var = var * (float)a.t.beta2 + (float)(1.0 - a.t.beta2) * (grad * grad);
+            const double step_size = a.t.lr / (1.0 - a.pow1);
+            const float bc2_sqrt = (float)__builtin_sqrt(1.0 - a.pow2);
+            const float denom = __builtin_sqrtf(var) / bc2_sqrt + (float)a.t.eps;
+            w = w - (float)step_size * (mom / denom);
+        } else {
+            mom = (a.t.step0 + a.batch_index == 0) ? grad : (float)a.t.momentum * mom + grad;
+            w = w - (float)a.t.lr * mom;
+        }
+        a.t.w[p] = w;
+        a.t.opt[p] = mom;
+        a.t.opt[NP + p] = var;
+    }
+    if (p == 0) {
+        float sum = 0.f;
+        for (int q = 0; q < B; ++q) sum += a.err2[q];
+        a.t.batch_loss[a.batch_index] = sum / (float)B;
     }
 }
 

@@ -1403,6 +1403,40 @@ int launch_train_net(const TrainArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return cnn_fail(nullptr, AUV_ERR_DEVICE, "k_train_net launch failed: %s", hipGetErrorString(e));
     return AUV_OK;
 }
+
+// the two-launch form: a workgroup per sample, then the update; scratch from the stream-ordered allocator
+extern "C++" template <int KIND>
+int launch_train_split(const TrainArgs& t, const auv_train_params* hp, hipStream_t stream) {
+    constexpr size_t lds = train_sample_lds_bytes(KIND);
+    static_assert(lds <= 64 * 1024, "a sample's activations and the parameters fit the default LDS limit");
+    constexpr int NPP = train_params_padded(KIND), NP = cnn_n_weights(KIND);
+    float* scratch = nullptr;
+    const size_t bytes = ((size_t)kTrainBatchMax * NPP + kTrainBatchMax) * sizeof(float);
+    if (hipMallocAsync((void**)&scratch, bytes, stream) != hipSuccess)
+        return cnn_fail(nullptr, AUV_ERR_MEMORY, "auv_train_cnn: %zu B of scratch refused", bytes);
+    TrainSplitArgs a;
+    a.t = t;
+    a.gsample = scratch;
+    a.err2 = scratch + (size_t)kTrainBatchMax * NPP;
+    double pow1 = 1.0, pow2 = 1.0;  // running products, as the one-launch kernels form them
+    for (long long s = 0; s < t.step0; ++s) {
+        pow1 *= hp->beta1;
+        pow2 *= hp->beta2;
+    }
+    for (long long b = 0; b < t.n_batches; ++b) {
+        pow1 *= hp->beta1;
+        pow2 *= hp->beta2;
+        a.batch_index = b;
+        a.pow1 = pow1;
+        a.pow2 = pow2;
+        hipLaunchKernelGGL(k_train_sample<KIND>, dim3((unsigned)t.batch), dim3(kTrainSampleThreads), lds, stream, a);
+        hipLaunchKernelGGL(k_train_update<KIND>, dim3((NP + 255) / 256), dim3(256), 0, stream, a);
+    }
+    hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(scratch, stream);
+    if (e != hipSuccess) return cnn_fail(nullptr, AUV_ERR_DEVICE, "k_train_sample launch failed: %s", hipGetErrorString(e));
+    return AUV_OK;
+}
 }  // namespace
 
 int auv_train_shallow(int device, const float* X, const float* y, int64_t n_rows, const int32_t* perm,
@@ -1431,7 +1465,7 @@ int auv_train_cnn(int32_t kind, int device, const float* X, const float* y, int6
                               steps_done, batch_loss, &a);
     if (rc != AUV_OK || n_batches == 0) return rc;
     return kind == AUV_CNN_2DEEP ? launch_train_net<CNN_2DEEP>(a, (hipStream_t)stream)
-                                 : launch_train_net<CNN_DEEP>(a, (hipStream_t)stream);
+                                 : launch_train_split<CNN_DEEP>(a, hp, (hipStream_t)stream);
 }
 
 int auv_risk_rows(auv_handle h, int64_t n, const double* own_speed, const double* own_heading,

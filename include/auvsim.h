@@ -405,8 +405,11 @@ int auv_train_shallow(int device, const float* X, const float* y, int64_t n_rows
  * trainer.py:18-43,144-151): kind = AUV_CNN_SHALLOW (59 parameters), AUV_CNN_2DEEP
  * (models/lidar_cnn_deep.py:110-146; 178) or AUV_CNN_DEEP (models/lidar_cnn_deep.py:19-82 with channels
  * [2,4,4,6], kernel 9; 3,723); weights [n] and opt_state [2n] for the network's n parameters, in the order
- * auv_cnn_create takes them.  One workgroup keeps the parameters, the batch's activations and their gradients
- * in LDS (121 KiB for the largest network) and runs every batch of the epoch in sequence. */
+ * auv_cnn_create takes them.  The two small networks: one workgroup keeps the parameters, the batch's
+ * activations and their gradients in LDS and runs every batch of the epoch in sequence, in one launch.
+ * AUV_CNN_DEEP: two launches per batch, enqueued for the whole epoch by this call (a workgroup per sample for
+ * forward and backward, then the optimizer step); its 233 KiB of scratch come from and return to the
+ * stream-ordered allocator (hipMallocAsync / hipFreeAsync on `stream`). */
 int auv_train_cnn(int32_t kind, int device, const float* X, const float* y, int64_t n_rows, const int32_t* perm,
                   int64_t n_batches, int32_t batch, float* weights, float* opt_state, const auv_train_params* hp,
                   int64_t steps_done, float* batch_loss, void* stream);
