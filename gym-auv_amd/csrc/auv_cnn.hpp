@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256) void k_cnn(CnnArgs a) {
 // LDS read at a fixed offset; a lane owns pooled position lo, reads its 10-wide
 // input window once and runs all output channels over it with the weights in
 // scalar registers (the channel loop is wave-uniform); the two linear layers
-// read transposed weights from LDS (lane = output, no bank conflicts).
+// read transposed weights (lane = output: consecutive floats per wave) made once
+// when the network is created, through the vector cache.
 // Accumulation order is that of conv_layer / linear_layer; products and sums
 // are fused (fmaf), which only tightens the result (tolerance-compared).
 constexpr int kDeepHaloL = 4, kDeepHaloR = 5;
@@ -317,9 +318,10 @@ constexpr int kDeepRowA = 216;  // floats per scan of buffer A: max(180+9, 4*(45
 constexpr int kDeepRowB = 200;  // buffer B: max(2*(90+9), 4*(23+9), 40)
 constexpr int kDeepL1T = 72 * 40, kDeepL2T = 40 * 8;
 
-__host__ __device__ inline size_t cnn_deep_lds_bytes() {
-    return ((size_t)kCnnScans * (kDeepRowA + kDeepRowB) + kDeepL1T + kDeepL2T) * sizeof(float);
-}
+__host__ __device__ inline size_t cnn_deep_lds_bytes() { return (size_t)kCnnScans * (kDeepRowA + kDeepRowB) * sizeof(float); }
+// floats of the deep network's device copy: the packed parameters, then linear_1.0.weight and linear_1.2.weight
+// transposed ([72][40] and [40][8]: lane = output, so a wave reads consecutive floats), made once at creation
+constexpr int kDeepWeightsDev = 3723 + kDeepL1T + kDeepL2T;
 
 // store v as logical element lo of a row of length Lo that carries halos
 __device__ __forceinline__ void put_with_halo(float* row, int Lo, int lo, float v) {
@@ -328,61 +330,82 @@ __device__ __forceinline__ void put_with_halo(float* row, int Lo, int lo, float 
     if (lo < kDeepHaloR) row[kDeepHaloL + Lo + lo] = v;
 }
 
+typedef float cnn_float2 __attribute__((ext_vector_type(2)));
+
+// The two conv positions under a pooled cell share every weight: they are the
+// two halves of one packed fused multiply-add.  Tap k needs (x[k], x[k+1]):
+// even taps take the pairs (x0,x1) (x2,x3) ..., odd taps the pairs (x1,x2) ...
 template <int CIN, int COUT, int L, bool LAST>
 __device__ __forceinline__ void deep_conv(const float* in, float* out, const float* w, const float* b, int lane) {
     constexpr int Lo = (L + 1) / 2;
     constexpr int LsI = L + kDeepHaloL + kDeepHaloR;
     constexpr int LsO = LAST ? Lo : Lo + kDeepHaloL + kDeepHaloR;
     for (int lo = lane; lo < Lo; lo += kCnnLanes) {
-        float x[CIN][10];  // inputs 2lo-4 .. 2lo+5 of every channel
+        // inputs 2lo-4 .. 2lo+5 of every channel, as even and odd pairs; the odd pairs are formed from the
+        // registers of the even ones (the CU's one LDS pipe is the scarcer unit here)
+        cnn_float2 xe[CIN][5], xo[CIN][4];
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci)
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float* r = in + ci * LsI + 2 * lo;
 #pragma unroll
-            for (int j = 0; j < 10; ++j) x[ci][j] = in[ci * LsI + 2 * lo + j];
+            for (int j = 0; j < 5; ++j) xe[ci][j] = cnn_float2{r[2 * j], r[2 * j + 1]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xo[ci][j] = cnn_float2{xe[ci][j].y, xe[ci][j + 1].x};
+        }
         const bool two = 2 * lo + 1 < L;  // the last pooled cell of an odd row covers one position
 #pragma nounroll
         for (int co = 0; co < COUT; ++co) {  // wave-uniform: weights come through the scalar unit
-            float a0 = b[co], a1 = b[co];
+            cnn_float2 acc = cnn_float2{b[co], b[co]};
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const float wv = w[(co * CIN + ci) * 9 + k];
-                    a0 = __builtin_fmaf(wv, x[ci][k], a0);
-                    a1 = __builtin_fmaf(wv, x[ci][k + 1], a1);
+                    acc = __builtin_elementwise_fma(cnn_float2{wv, wv}, (k & 1) ? xo[ci][k >> 1] : xe[ci][k >> 1], acc);
                 }
-            a0 = a0 > 0.f ? a0 : 0.f;
-            a1 = a1 > 0.f ? a1 : 0.f;
-            const float v = (two && a1 > a0) ? a1 : a0;
-            if (LAST) out[co * LsO + lo] = v;
-            else put_with_halo(out + co * LsO, Lo, lo, v);
+            // ReLU then the larger of the pair = the largest of the two sums and zero
+            const float a1 = ((L & 1) && !two) ? acc.x : acc.y;
+            const float v = __builtin_fmaxf(__builtin_fmaxf(acc.x, a1), 0.f);
+            out[co * LsO + (LAST ? 0 : kDeepHaloL) + lo] = v;
+        }
+    }
+    if (!LAST) {
+        // the rows' circular halos, copied once the rows are complete: 4 cells before, 5 behind, per channel
+        layer_sync<false>();
+        for (int i = lane; i < COUT * (kDeepHaloL + kDeepHaloR); i += kCnnLanes) {
+            const int co = i / (kDeepHaloL + kDeepHaloR), h = i - co * (kDeepHaloL + kDeepHaloR);
+            float* row = out + co * LsO;
+            if (h < kDeepHaloL) row[h] = row[Lo + h];                       // cell Lo - 4 + h
+            else row[Lo + h] = row[h];                                      // cell h - 4 behind the end
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_cnn_deep(CnnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_cnn_deep(CnnArgs a) {
     extern __shared__ __align__(16) float cnn_lds[];
     float* bufA = cnn_lds;                                   // [kCnnScans][kDeepRowA]
     float* bufB = bufA + kCnnScans * kDeepRowA;               // [kCnnScans][kDeepRowB]
-    float* w1t = bufB + kCnnScans * kDeepRowB;                // [72][40] = linear_1.0.weight transposed
-    float* w2t = w1t + kDeepL1T;                              // [40][8]  = linear_1.2.weight transposed
     const int tid = threadIdx.x;
     const long long s0 = (long long)blockIdx.x * kCnnScans;
     const int ns = (int)((a.B - s0) < kCnnScans ? (a.B - s0) : kCnnScans);
     const float* w = a.w;
-    // packed order: c1.w[18] b[2] c2.w[72] b[4] c3.w[144] b[4] c4.w[216] b[6] l1.w[2880] b[40] l2.w[320] b[8] l3.w[8] b[1]
-    for (int i = tid; i < kDeepL1T; i += 256) {
-        const int o = i / 72, k = i - o * 72;
-        w1t[k * 40 + o] = w[466 + i];
-    }
-    for (int i = tid; i < kDeepL2T; i += 256) {
-        const int o = i / 40, k = i - o * 40;
-        w2t[k * 8 + o] = w[3386 + i];
-    }
-    // the tile's scans, each into a row with its circular halo
-    for (int i = tid; i < ns * kCnnLen; i += 256) {
-        const int s = i / kCnnLen, f = i - s * kCnnLen;
-        put_with_halo(bufA + s * kDeepRowA, kCnnLen, f, a.scans[s0 * kCnnLen + i]);
+    // packed order: c1.w[18] b[2] c2.w[72] b[4] c3.w[144] b[4] c4.w[216] b[6] l1.w[2880] b[40] l2.w[320] b[8] l3.w[8] b[1],
+    // then the two transposed linear weights (kDeepWeightsDev)
+    const float* w1t = w + 3723;            // [72][40]
+    const float* w2t = w1t + kDeepL1T;      // [40][8]
+    // the tile's scans, each into a row with its circular halo, in 16-byte pieces (45 per scan; rows and the
+    // tile's first scan start at multiples of 16 B): the last piece is also the left halo, the first one and the
+    // first float of the second the right halo
+    static_assert(kDeepHaloL == 4 && kDeepHaloR == 5 && kDeepRowA % 4 == 0 && kCnnLen % 4 == 0, "halo pieces");
+    const float4* src = reinterpret_cast<const float4*>(a.scans + s0 * kCnnLen);
+    for (int i = tid; i < ns * (kCnnLen / 4); i += 256) {
+        const int sc = i / (kCnnLen / 4), c = i - sc * (kCnnLen / 4);
+        const float4 v = src[i];
+        float* row = bufA + sc * kDeepRowA;
+        *reinterpret_cast<float4*>(row + kDeepHaloL + 4 * c) = v;
+        if (c == kCnnLen / 4 - 1) *reinterpret_cast<float4*>(row) = v;
+        if (c == 0) *reinterpret_cast<float4*>(row + kDeepHaloL + kCnnLen) = v;
+        if (c == 1) row[kDeepHaloL + kCnnLen + 4] = v.x;
     }
     __syncthreads();
     const int s = tid / kCnnLanes;
@@ -398,20 +421,53 @@ __global__ __launch_bounds__(256) void k_cnn_deep(CnnArgs a) {
     layer_sync<false>();
     deep_conv<4, 6, 23, true>(B, A, w + 244, w + 460, lane);    // 6 x 12, plain rows = the 72 inputs of linear 1
     layer_sync<false>();
-    for (int o = lane; o < 40; o += kCnnLanes) {
-        float acc = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < 72; ++k) acc = __builtin_fmaf(A[k], w1t[k * 40 + o], acc);
-        acc += w[3346 + o];
-        B[o] = acc > 0.f ? acc : 0.f;
+    {
+        // Linear(72 -> 40) + ReLU: a lane owns outputs lane, lane + 16, lane + 32; the 72 inputs come from LDS
+        // four at a time and serve the three; each output is summed over k in order
+        const float4* A4 = reinterpret_cast<const float4*>(A);  // rows start at multiples of 16 B
+        const int o2 = lane + 32 < 40 ? lane + 32 : 39;         // lanes 8..15 have no third output: a harmless repeat
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll 3
+        for (int k4 = 0; k4 < 18; ++k4) {
+            const float4 v = A4[k4];
+            const float* wr = w1t + k4 * 160;
+            c0 = __builtin_fmaf(v.x, wr[lane], c0);
+            c1 = __builtin_fmaf(v.x, wr[lane + 16], c1);
+            c2 = __builtin_fmaf(v.x, wr[o2], c2);
+            c0 = __builtin_fmaf(v.y, wr[40 + lane], c0);
+            c1 = __builtin_fmaf(v.y, wr[40 + lane + 16], c1);
+            c2 = __builtin_fmaf(v.y, wr[40 + o2], c2);
+            c0 = __builtin_fmaf(v.z, wr[80 + lane], c0);
+            c1 = __builtin_fmaf(v.z, wr[80 + lane + 16], c1);
+            c2 = __builtin_fmaf(v.z, wr[80 + o2], c2);
+            c0 = __builtin_fmaf(v.w, wr[120 + lane], c0);
+            c1 = __builtin_fmaf(v.w, wr[120 + lane + 16], c1);
+            c2 = __builtin_fmaf(v.w, wr[120 + o2], c2);
+        }
+        c0 += w[3346 + lane];
+        c1 += w[3346 + lane + 16];
+        c2 += w[3346 + o2];
+        B[lane] = c0 > 0.f ? c0 : 0.f;
+        B[lane + 16] = c1 > 0.f ? c1 : 0.f;
+        if (lane + 32 < 40) B[lane + 32] = c2 > 0.f ? c2 : 0.f;
     }
     layer_sync<false>();
     float feat = 0.f;
-    if (lane < 8) {
+    {
+        // Linear(40 -> 8): lanes 0..7 own an output each (the others repeat one and drop it)
+        const float4* B4 = reinterpret_cast<const float4*>(B);
+        const int o = lane & 7;
         float acc = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < 40; ++k) acc = __builtin_fmaf(B[k], w2t[k * 8 + lane], acc);
-        feat = acc + w[3706 + lane];
+#pragma unroll 5
+        for (int k4 = 0; k4 < 10; ++k4) {
+            const float4 v = B4[k4];
+            const float* wr = w2t + k4 * 32 + o;
+            acc = __builtin_fmaf(v.x, wr[0], acc);
+            acc = __builtin_fmaf(v.y, wr[8], acc);
+            acc = __builtin_fmaf(v.z, wr[16], acc);
+            acc = __builtin_fmaf(v.w, wr[24], acc);
+        }
+        feat = acc + w[3706 + o];
     }
     float* out = a.out + (s0 + s) * cnn_out_dim(CNN_DEEP, a.head);
     if (a.head == HEAD_FEATURES) {

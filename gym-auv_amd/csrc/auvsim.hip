@@ -1307,8 +1307,17 @@ int auv_cnn_create(int32_t kind, const float* weights, int64_t n_weights, int de
     auv_cnn* c = new auv_cnn();
     c->kind = kind;
     c->device = device;
-    if (hipMalloc((void**)&c->w, (size_t)n_weights * sizeof(float)) != hipSuccess ||
-        hipMemcpy(c->w, weights, (size_t)n_weights * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    // the deep network's copy also holds its two larger linear weights transposed (k_cnn_deep reads them by output)
+    std::vector<float> host(weights, weights + n_weights);
+    if (kind == CNN_DEEP) {
+        host.resize(kDeepWeightsDev);
+        for (int o = 0; o < 40; ++o)
+            for (int k = 0; k < 72; ++k) host[3723 + (size_t)k * 40 + o] = weights[466 + o * 72 + k];
+        for (int o = 0; o < 8; ++o)
+            for (int k = 0; k < 40; ++k) host[3723 + kDeepL1T + (size_t)k * 8 + o] = weights[3386 + o * 40 + k];
+    }
+    if (hipMalloc((void**)&c->w, host.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(c->w, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         if (c->w) (void)hipFree(c->w);
         delete c;
         return cnn_fail(nullptr, AUV_ERR_MEMORY, "auv_cnn_create: weight upload failed");
@@ -1510,7 +1519,8 @@ int auv_attach_cnn(auv_handle h, auv_cnn_handle c, int32_t head) {
     if (c->device != h->device)
         return fail(h, AUV_ERR_ARG, "auv_attach_cnn: network lives on device %d, batch on %d", c->device, h->device);
     float* w = nullptr;
-    const size_t nb = (size_t)cnn_n_weights(c->kind) * sizeof(float);
+    // the deep network's device copy carries its transposed linear weights behind the parameters
+    const size_t nb = (size_t)(c->kind == CNN_DEEP ? kDeepWeightsDev : cnn_n_weights(c->kind)) * sizeof(float);
     HIP_TRY(h, hipMalloc((void**)&w, nb));
     if (hipMemcpy(w, c->w, nb, hipMemcpyDeviceToDevice) != hipSuccess) {
         (void)hipFree(w);
