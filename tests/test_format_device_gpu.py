@@ -1,6 +1,8 @@
 """The dataset text formed on the device (`auv_format_rows_device`, `DeviceRowFormatter`,
 `DeviceDatasetLogger`) against the host formatter (itself held to printf's "%.18e" by
 tests/test_dataset_cpu.py) and against Python's own "%.18e": byte for byte."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -115,4 +117,39 @@ def test_device_logger_writes_the_host_loggers_files(tmp_path):
     with pytest.raises(ValueError):
         host_only = D.DeviceDatasetLogger(sim, wd)
         host_only.samples()
+    sim.close()
+
+
+def test_device_logger_at_the_dense_configurations_full_size(tmp_path):
+    """The dense 720-ray scene at its full size (4,096 vessels, 256 obstacles each): two logged steps through both
+    loggers, 8,192 rows and ~230 MB of text per logger, equal byte for byte (compared through digests)."""
+    import hashlib
+
+    cfg, scene = scenarios.make_workload("cfg5_dense_720")
+    V = cfg["n_envs"]
+    sim = AuvSim(cfg)
+    sim.set_scene(scene)
+    sim.reset(scene["init_state"])
+    wh, wd = D.DatasetWriter(str(tmp_path / "host")), D.DatasetWriter(str(tmp_path / "dev"))
+    host, dev = D.DatasetLogger(sim, wh), D.DeviceDatasetLogger(sim, wd)
+    acts = scenarios.random_actions(V, 10, seed=3)
+    for k in range(10):
+        sim.step_host(acts[k])
+        assert host.after_step() == dev.after_step()
+    wh.close()
+    wd.close()
+    assert wh.rows == wd.rows == 2 * V
+
+    def digest(path):
+        h = hashlib.sha256()
+        with open(path, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 24), b""):
+                h.update(chunk)
+        return h.hexdigest(), os.path.getsize(path)
+
+    for kind in ("LiDAR", "risk", "metadata"):
+        a, b = digest(wh.paths[kind]), digest(wd.paths[kind])
+        assert a == b and a[1] > 0, kind
+    assert digest(wd.paths["LiDAR"])[1] == 2 * V * 720 * 25      # ranges are never negative: 24 characters and a separator each
+    assert sum(f.host_fallbacks for f in dev._fmt.values()) == 0
     sim.close()
