@@ -380,7 +380,9 @@ const char* auv_cnn_last_error(auv_cnn_handle c);
  * pointers but `hp` are DEVICE memory on `device`:
  *   X [n_rows,180] f32 scans (closeness), y [n_rows] f32 labels,
  *   perm [n_batches*batch] i32 row index of every slot of every batch (the
- *   DataLoader's shuffle, utils/dataloader.py:76-80; batch <= 16),
+ *   DataLoader's shuffle, utils/dataloader.py:76-80; batch <= 16); every entry
+ *   must lie in [0, n_rows): the kernels index X and y with it unchecked (it is
+ *   device memory; trainer.DeviceTrainer checks it on the host before the upload),
  *   weights [59] f32 in/out (state-dict order, as auv_cnn_create takes them),
  *   opt_state [118] f32 in/out (AdamW: exp_avg, exp_avg_sq; SGD: momentum
  *   buffer; zeros before the first step), batch_loss [n_batches] f32 out (what
