@@ -419,12 +419,37 @@ def split_sizes(n, train_test_split=0.7, train_val_split=0.2):
     return train - val, val, n - train
 
 
-def load_lidar_dataset(path_x, path_y, mode=None, train_test_split=0.7, train_val_split=0.2):
+def _binary_rows(npz_path, mode):
+    """(ranges, labels) of the rows `export_csv` would write from a `save_binary` file, without the text:
+    samples with a tracked obstacle, the label over at most 8 of the tracked obstacles' risks in id order."""
+    d = np.load(npz_path)
+    tracked = d["tracked"].astype(bool)
+    keep = tracked.any(axis=1)
+    ranges, risk, tracked = d["ranges"][keep], d["risk"][keep], tracked[keep]
+    order = np.argsort(~tracked, axis=1, kind="stable")
+    risk_c = np.take_along_axis(risk, order, axis=1)
+    cnt = tracked.sum(axis=1)
+    y = np.empty(len(ranges))
+    for i in range(len(ranges)):
+        r = risk_c[i, :min(cnt[i], 8)]
+        y[i] = r.max() if mode == "max" else r.sum() if mode == "sum" else r.mean()
+    return ranges, y
+
+
+def load_lidar_dataset(path_x, path_y=None, mode=None, train_test_split=0.7, train_val_split=0.2):
     """Arrays of the three splits as the reference builds them
     (utils/dataloader.py:44-101): X = 1 - X/150 with a channel dimension,
-    float32; y reduced by `mode` (None: the file holds one label per row)."""
-    X = 1.0 - np.loadtxt(path_x) / SENSOR_RANGE
-    y = np.loadtxt(path_y) if mode is None else calculate_total_risk(path_y, mode)
+    float32; y reduced by `mode` (None: the file holds one label per row).
+    `path_x` may instead be a `save_binary` file (.npz; `path_y` unused, `mode`
+    required): the same arrays as from the text files `export_csv` makes of it."""
+    if str(path_x).endswith(".npz"):
+        if mode is None:
+            raise ValueError("a binary dataset holds per-obstacle risks: give mode 'max', 'sum' or 'mean'")
+        ranges, y = _binary_rows(path_x, mode)
+        X = 1.0 - ranges / SENSOR_RANGE
+    else:
+        X = 1.0 - np.loadtxt(path_x) / SENSOR_RANGE
+        y = np.loadtxt(path_y) if mode is None else calculate_total_risk(path_y, mode)
     n_train, n_val, n_test = split_sizes(len(X), train_test_split, train_val_split)
     sl = {"train": slice(0, n_train), "val": slice(n_train, n_train + n_val), "test": slice(len(X) - n_test, len(X))}
     out = {k: (X[s].astype(np.float32)[:, None, :], y[s].astype(np.float32)[:, None]) for k, s in sl.items()}

@@ -188,3 +188,32 @@ def test_writer_appends_behind_existing_rows_and_splits_large_blocks(tmp_path):
     assert open(w.paths["LiDAR"], "rb").read() == b"".join(D.format_rows(b) for b in blocks)
     assert np.array_equal(np.loadtxt(w.paths["risk"]), np.concatenate(blocks)[:, :2])
     assert np.array_equal(np.loadtxt(w.paths["metadata"]), np.concatenate(blocks)[:, :3])
+
+
+@pytest.mark.parametrize("mode", ["max", "sum", "mean"])
+def test_loader_reads_the_binary_sink_as_it_reads_the_exported_text(tmp_path, mode):
+    """save_binary -> load_lidar_dataset(.npz) equals save_binary -> export_csv -> load_lidar_dataset(text)."""
+    from gym_auv_amd import dataset as D
+
+    rng = np.random.default_rng(5)
+    n, O = 90, 12
+    ranges = rng.uniform(0.0, 150.0, (n, 180))
+    own, meta = rng.uniform(-3, 3, (n, 2)), rng.uniform(-3, 150, (n, O, 5))
+    risk = rng.uniform(0, 1, (n, O))
+    tracked = rng.uniform(size=(n, O)) < 0.3
+    tracked[:5] = False                      # samples without a tracked obstacle are not rows
+    tracked[5] = True                        # more than 8 listed: the label looks at the first 8 only
+    npz = str(tmp_path / "rows.npz")
+    D.save_binary(npz, ranges, own, meta, risk, tracked)
+    rows = D.export_csv(npz, str(tmp_path))
+    assert rows == int(tracked.any(axis=1).sum())
+    w = D.DatasetWriter(str(tmp_path))
+    paths = w.paths
+    w.close()
+    a = D.load_lidar_dataset(paths["LiDAR"], paths["risk"], mode=mode)
+    b = D.load_lidar_dataset(npz, mode=mode)
+    for k in ("train", "val", "test"):
+        assert np.array_equal(a[k][0], b[k][0]) and np.array_equal(a[k][1], b[k][1]), k
+    assert a["x_mean"] == b["x_mean"] and a["x_std"] == b["x_std"]
+    with pytest.raises(ValueError):
+        D.load_lidar_dataset(npz)
