@@ -35,12 +35,12 @@ __device__ __forceinline__ float fast_atan2f(float y, float x) {
     const float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
     const float z = lo * __builtin_amdgcn_rcpf(hi);
     const float z2 = z * z;
-    float p = -0.011719128f;
-    p = 0.052647337f + z2 * p;
-    p = -0.116426475f + z2 * p;
-    p = 0.193540379f + z2 * p;
-    p = -0.332622826f + z2 * p;
-    p = 0.999977231f + z2 * p;
+    float p = -0.011719128f;  // fused steps: an estimate for the culls, not part of the exact arithmetic
+    p = __builtin_fmaf(z2, p, 0.052647337f);
+    p = __builtin_fmaf(z2, p, -0.116426475f);
+    p = __builtin_fmaf(z2, p, 0.193540379f);
+    p = __builtin_fmaf(z2, p, -0.332622826f);
+    p = __builtin_fmaf(z2, p, 0.999977231f);
     float a = z * p;
     a = ay > ax ? 1.57079633f - a : a;
     a = x < 0.0f ? 3.14159265f - a : a;
@@ -61,8 +61,8 @@ __device__ __forceinline__ int fast_div(int i, float inv_d) { return (int)(((flo
 __device__ __forceinline__ float scan_index(float bearing, float psi, float inv_delta) {
     float w = bearing - psi;
     const float two_pi = 6.2831853f, pi = 3.14159265f;
-    w = w - two_pi * floorf((w + pi) * (1.0f / two_pi));
-    return (w + pi) * inv_delta - 1.0f;
+    w = __builtin_fmaf(-two_pi, floorf((w + pi) * (1.0f / two_pi)), w);
+    return __builtin_fmaf(w + pi, inv_delta, -1.0f);
 }
 
 __device__ __forceinline__ int2 make_interval(float lo, float hi, int R, float margin) {

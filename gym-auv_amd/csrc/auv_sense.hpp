@@ -653,7 +653,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                 prim = i;
                 const double* c4 = circ + 4 * i;
                 const float fr = (float)c4[3], fmx = (float)c4[0], fmy = (float)c4[1];
-                const float fmm = fmx * fmx + fmy * fmy;
+                const float fmm = __builtin_fmaf(fmx, fmx, fmy * fmy);
                 if (!(fr > 0.0f)) {
                     // absent slot
                 } else if (!(fmm > fr * fr * 1.001f)) {
@@ -662,7 +662,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                     // wholly beyond sensor range
                 } else {
                     const float xc = scan_index(fast_atan2f(fmy, fmx), (float)env[2 * TE + el], inv_delta);
-                    const float hw = fast_atan2f(fr, fast_sqrtf(fmm - fr * fr)) * inv_delta;
+                    const float hw = fast_atan2f(fr, fast_sqrtf(__builtin_fmaf(-fr, fr, fmm))) * inv_delta;
                     iv = make_interval(xc - hw, xc + hw, R, margin);
                 }
             }
@@ -686,7 +686,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                 const float fax = (float)sg[0], fay = (float)sg[1], fex = (float)sg[2], fey = (float)sg[3];
                 const float fbx = fax + fex, fby = fay + fey;
                 const float dmin = fast_sqrtf((float)edist[i]);
-                const float aa = fax * fax + fay * fay, bb = fbx * fbx + fby * fby;
+                const float aa = __builtin_fmaf(fax, fax, fay * fay), bb = __builtin_fmaf(fbx, fbx, fby * fby);
                 if (aa < 1e-6f || bb < 1e-6f || dmin < 1e-3f) {
                     iv.y = R;  // an endpoint (or the edge) is on top of the vessel: bearings are meaningless
                 } else {
