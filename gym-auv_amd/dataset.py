@@ -126,6 +126,12 @@ class DatasetWriter:
             self._pool.shutdown()
             self._pool = None
 
+    def __del__(self):
+        try:
+            self.close()        # raw descriptors are not closed by the garbage collector
+        except Exception:
+            pass
+
     def __enter__(self):
         return self
 
