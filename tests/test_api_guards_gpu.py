@@ -108,3 +108,49 @@ def test_cnn_forward_checks_its_output_tensor():
             net.forward(x, "risk", out=bad)
     assert net.forward(x, "risk", out=torch.empty(5, 1, device="cuda")).shape == (5, 1)
     net.close()
+
+
+def test_a_rollout_can_be_captured_into_a_graph_and_replays_bit_for_bit():
+    """Stepping with resident actions allocates nothing and never synchronises, so a rollout can be captured on a
+    stream (HIP graph) as it is; replaying the graph must leave every buffer as plain stepping leaves it, episodes
+    restarting inside the steps included."""
+    import torch
+
+    from gym_auv_amd.sim import AuvSim
+
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=1000)
+    cfg["max_steps"] = 17                       # every episode ends inside the rollout and restarts on the device
+    acts = torch.from_numpy(scenarios.random_actions(1000, 8, seed=5)).cuda()
+    ptrs = [acts[i].data_ptr() for i in range(8)]
+    K, got = 40, {}
+    for mode in ("plain", "graph"):
+        sim = AuvSim(cfg)
+        sim.set_scene(scene)
+        sim.set_option(_lib.OPT_AUTO_RESET, 1)
+        st = torch.cuda.current_stream()
+        if mode == "graph":
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):       # a first launch outside the capture
+                sim.reset(scene["init_state"], stream=side)
+                sim.step_device(ptrs[0], stream=side)
+            torch.cuda.synchronize()
+        sim.reset(scene["init_state"], stream=st)
+        torch.cuda.synchronize()
+        if mode == "plain":
+            for k in range(K):
+                sim.step_device(ptrs[k % 8], stream=st)
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                s = torch.cuda.current_stream()
+                for k in range(K):
+                    sim.step_device(ptrs[k % 8], stream=s)
+            assert int(sim.read("t_step").max()) == 0      # capturing executed nothing
+            g.replay()
+        torch.cuda.synchronize()
+        got[mode] = {k: sim.read(k).copy() for k in ("state", "ranges", "hit", "perception", "obst_dist", "meta", "risk",
+                                                     "reward", "done", "t_step", "circles", "poly_pose")}
+        sim.close()
+    assert int(got["plain"]["t_step"].max()) < K           # restarts happened
+    for k, v in got["plain"].items():
+        assert np.array_equal(v, got["graph"][k], equal_nan=True), k
