@@ -126,3 +126,14 @@ def gather_scans(perception: torch.Tensor, dst: int = 0, group=None, out: torch.
         return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
     dist.gather(send, None, dst=dst, group=group)
     return None
+
+
+def gather_samples(X: torch.Tensor, y: torch.Tensor, dst: int = 0, group=None):
+    """The training samples every rank collected from its envs
+    (`dataset.DeviceDatasetLogger.samples()`: X `[n_local,1,R]`, y `[n_local,1]`)
+    on the trainer rank `dst`, in rank order; ranks hold different numbers of
+    rows.  Returns (X, y) on `dst`, (None, None) elsewhere; what the trainer
+    rank then hands to `trainer.DeviceTrainer`."""
+    if len(X) != len(y):
+        raise ValueError("X and y differ in length")
+    return gather_scans(X, dst, group), gather_scans(y, dst, group)

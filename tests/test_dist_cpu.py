@@ -136,6 +136,41 @@ def test_equal_shards_gather_in_place():
     assert np.array_equal(out, want.astype(np.float32))
 
 
+def _samples_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 5 if rank == 0 else 9                   # ranks log different numbers of rows
+        X = torch.full((n, 1, 180), float(rank + 1)) + torch.arange(n, dtype=torch.float32)[:, None, None] / 100.0
+        y = torch.arange(n, dtype=torch.float32)[:, None] + 10.0 * rank
+        gx, gy = D.gather_samples(X, y, dst=0)
+        q.put((gx.numpy(), gy.numpy()) if rank == 0 else (gx, gy))
+    finally:
+        tdist.destroy_process_group()
+
+
+def test_samples_of_unequal_shards_reach_the_trainer_rank_in_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_samples_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sum(g == (None, None) for g in got if not isinstance(g[0], np.ndarray)) == 1
+    gx, gy = [g for g in got if isinstance(g[0], np.ndarray)][0]
+    assert gx.shape == (14, 1, 180) and gy.shape == (14, 1)
+    assert np.array_equal(gy[:, 0], np.concatenate([np.arange(5.0), np.arange(9.0) + 10.0]).astype(np.float32))
+    assert np.array_equal(gx[:, 0, 0], np.concatenate([1.0 + np.arange(5) / 100.0, 2.0 + np.arange(9) / 100.0]).astype(np.float32))
+    with pytest.raises(ValueError):
+        D.gather_samples(torch.zeros(3, 1, 180), torch.zeros(2, 1))
+    x1, y1 = D.gather_samples(torch.zeros(3, 1, 180), torch.zeros(3, 1))       # no group: the tensors themselves
+    assert x1.shape == (3, 1, 180) and y1.shape == (3, 1)
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2`, not under torchrun, must come back as a two-rank run.  There is no GPU here, so
     the ranks rehearse everything but the simulation (AUV_BENCH_REHEARSE=nogpu): launch, rendezvous, barrier,
