@@ -153,3 +153,22 @@ def test_device_logger_at_the_dense_configurations_full_size(tmp_path):
     assert digest(wd.paths["LiDAR"])[1] == 2 * V * 720 * 25      # ranges are never negative: 24 characters and a separator each
     assert sum(f.host_fallbacks for f in dev._fmt.values()) == 0
     sim.close()
+
+
+def test_two_million_random_bit_patterns():
+    """Uniformly random significands at every binary exponent the device covers (2^-119 .. 2^59, i.e. 1.5e-36 ..
+    5.8e17), both signs: the device's text equals the host formatter's everywhere and Python's on a sample."""
+    rng = np.random.default_rng(2026)
+    n, stride = 4000, 500
+    expo = rng.integers(1023 - 119, 1023 + 59, n * stride, dtype=np.uint64)
+    bits = (rng.integers(0, 2, n * stride, dtype=np.uint64) << np.uint64(63)) | (expo << np.uint64(52)) \
+        | rng.integers(0, 1 << 52, n * stride, dtype=np.uint64)
+    vals = bits.view(np.float64).reshape(n, stride)
+    assert np.isfinite(vals).all() and (np.abs(vals) >= 1e-36).all() and (np.abs(vals) < 1e18).all()
+    f = D.DeviceRowFormatter(0)
+    got = bytes(f.fetch(f.format(torch.from_numpy(vals).cuda())))
+    assert f.host_fallbacks == 0
+    assert got == D.format_rows(vals)
+    lines = got.split(b"\n")
+    for i in rng.integers(0, n, 40):
+        assert lines[i] == " ".join("%.18e" % x for x in vals[i]).encode(), i
