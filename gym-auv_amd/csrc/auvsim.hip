@@ -1233,8 +1233,8 @@ int64_t auv_format_rows(const double* values, const int32_t* row_len, int64_t n_
 
 int auv_format_rows_device(int device, const double* values, const int32_t* row_len, int64_t n_rows, int64_t stride,
                            char* text, int64_t text_cap, int64_t* row_off, int32_t* status, void* stream) {
-    if (!values || !text || !row_off || !status) return AUV_ERR_ARG;
     if (n_rows < 0 || n_rows > 0x7fffffffLL || stride < 1 || text_cap < 0) return AUV_ERR_ARG;
+    if ((!values && n_rows > 0) || !text || !row_off || !status) return AUV_ERR_ARG;  // no rows: nothing is read
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return AUV_ERR_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return AUV_ERR_DEVICE;
@@ -1365,8 +1365,7 @@ namespace {
 int train_args(const char* who, int device, const float* X, const float* y, int64_t n_rows, const int32_t* perm,
                int64_t n_batches, int32_t batch, float* weights, float* opt_state, const auv_train_params* hp,
                int64_t steps_done, float* batch_loss, TrainArgs* a) {
-    if (!X || !y || !perm || !weights || !opt_state || !hp || !batch_loss)
-        return cnn_fail(nullptr, AUV_ERR_ARG, "%s: null argument", who);
+    if (!hp) return cnn_fail(nullptr, AUV_ERR_ARG, "%s: null argument", who);
     if (batch < 1 || batch > AUV_TRAIN_BATCH_MAX)
         return cnn_fail(nullptr, AUV_ERR_ARG, "%s: batch must be in 1..%d, got %d", who, AUV_TRAIN_BATCH_MAX, batch);
     if (n_rows < 1 || n_batches < 0 || steps_done < 0)
@@ -1374,7 +1373,9 @@ int train_args(const char* who, int device, const float* X, const float* y, int6
     if (hp->optimizer != AUV_OPT_ADAMW && hp->optimizer != AUV_OPT_SGD_MOMENTUM)
         return cnn_fail(nullptr, AUV_ERR_ARG, "%s: unknown optimizer %d", who, hp->optimizer);
     if (!(hp->lr > 0.0)) return cnn_fail(nullptr, AUV_ERR_ARG, "%s: lr must be positive", who);
-    if (n_batches == 0) return AUV_OK;
+    if (n_batches == 0) return AUV_OK;  // an epoch of fewer rows than one batch: nothing is read or written
+    if (!X || !y || !perm || !weights || !opt_state || !batch_loss)
+        return cnn_fail(nullptr, AUV_ERR_ARG, "%s: null argument", who);
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
         return cnn_fail(nullptr, AUV_ERR_DEVICE, "%s: no HIP device %d", who, device);

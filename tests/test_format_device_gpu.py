@@ -65,6 +65,9 @@ def test_values_outside_the_devices_range_take_the_host_formatter():
     tail = f.tail(t).cpu()
     assert int(tail[1]) == 7                      # everything but 1.0 and 2.0 is counted
     assert bytes(f.fetch(t)) == D.format_rows(vals) and f.host_fallbacks == 1
+    # no rows at all: no text
+    t = f.format(torch.zeros((0, 7), dtype=torch.float64, device="cuda"))
+    assert bytes(f.fetch(t)) == b"" == D.format_rows(np.zeros((0, 7)))
     with pytest.raises(ValueError):
         f.format(torch.zeros(3, 3, device="cuda"))            # float32
     with pytest.raises(ValueError):

@@ -81,6 +81,14 @@ def test_device_trainer_refuses_other_models():
         t.train_epoch(torch.arange(32) + 1)        # row 32 does not exist
     with pytest.raises(ValueError):
         t.train_epoch(torch.arange(20))            # two batches of 16 need 32 row numbers
+    # fewer rows than one batch: an epoch without a step (drop_last), parameters untouched
+    for kind in ("shallow", "deep2", "deep"):
+        model = MODELS[kind]()
+        before = {k: v.clone() for k, v in model.state_dict().items()}
+        small = T.DeviceTrainer(model, 1, 1e-3, *_data(10, 0))
+        assert small.train_epoch().numel() == 0 and small.steps_done == 0
+        small.sync_model()
+        assert all(torch.equal(v, before[k]) for k, v in model.state_dict().items())
 
 
 @pytest.mark.parametrize("kind,col,epochs,lr", [("shallow", 0, 12, 2e-3), ("deep2", 1, 12, 2e-3), ("deep", 2, 12, 1e-3)])
