@@ -142,7 +142,7 @@ class DeviceTrainer:
 
     @torch.no_grad()
     def validation_step(self):
-        if self.Xv is None:
+        if self.Xv is None or len(self.Xv) == 0:
             return float("nan")
         from .cnn import LidarCNN
 
