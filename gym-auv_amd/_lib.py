@@ -42,6 +42,7 @@ RISK_CPA, RISK_REFERENCE = 0, 1
 STATS_FIELDS = 8
 SIZES_UNIFORM, SIZES_BELL = 0, 1
 OPT_ADAMW, OPT_SGD_MOMENTUM = 0, 1
+ROWS_LABEL = {None: 0, "max": 1, "sum": 2, "mean": 3}
 TRAIN_BATCH_MAX = 16
 STATS_MAX_ENVS = 1048576
 
@@ -55,7 +56,7 @@ EXPORTS = (
     "auv_set_scene", "auv_reset", "auv_step", "auv_step_host", "auv_sense",
     "auv_get_buffer", "auv_read_buffer", "auv_dlpack", "auv_sync", "auv_set_option",
     "auv_profile_enable", "auv_cnn_n_weights", "auv_cnn_out_dim", "auv_cnn_create", "auv_cnn_destroy",
-    "auv_cnn_forward", "auv_cnn_last_error", "auv_format_rows", "auv_format_rows_device",
+    "auv_cnn_forward", "auv_cnn_last_error", "auv_format_rows", "auv_format_rows_device", "auv_dataset_rows",
     "auv_profile_read", "auv_attach_cnn", "auv_generate_scene", "auv_host_alloc", "auv_host_free",
     "auv_risk_rows", "auv_episode_stats", "auv_episode_stats_static", "auv_train_shallow", "auv_train_cnn", "auv_set_path",
 )
@@ -148,6 +149,8 @@ def load():
     lib.auv_profile_read.argtypes = [vp, dp, C.POINTER(i64)]
     lib.auv_format_rows.restype = i64
     lib.auv_format_rows.argtypes = [vp, vp, i64, i64, vp, i64]
+    lib.auv_dataset_rows.restype = C.c_int
+    lib.auv_dataset_rows.argtypes = [vp, i32, i32, i32, i32, i32] + [vp] * 11
     lib.auv_format_rows_device.restype = C.c_int
     lib.auv_format_rows_device.argtypes = [C.c_int, vp, vp, i64, i64, vp, i64, vp, vp, vp]
     lib.auv_cnn_n_weights.restype = C.c_int

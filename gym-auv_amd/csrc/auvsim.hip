@@ -24,6 +24,7 @@
 #include "auv_stats.hpp"
 #include "auv_train.hpp"
 #include "auv_format_device.hpp"
+#include "auv_dataset_rows.hpp"
 
 using namespace auv;
 
@@ -1191,6 +1192,65 @@ int auv_episode_stats_static(auv_handle h, double* out, int32_t accumulate, void
     double* records = g_scratch_ptr[h->device];  // resolved by auv_create on this device
     if (!records) return fail(h, AUV_ERR_STATE, "auv_episode_stats_static: scratch array of device %d unresolved", h->device);
     return launch_stats(h, records, out, accumulate, pick(h, stream));
+}
+
+// ---- dataset rows assembled on the device ------------------------------------
+
+int auv_dataset_rows(auv_handle h, int32_t phase, int32_t every, int32_t refresh_every, int32_t first, int32_t label_mode,
+                     uint8_t* tracked, int64_t* row_of, int32_t* due_count, double* lidar_rows, double* risk_rows,
+                     double* meta_rows, int32_t* risk_len, int32_t* meta_len, float* x_rows, float* label, void* stream) {
+    if (!h) return AUV_ERR_ARG;
+    if (every < 1 || refresh_every < 1) return fail(h, AUV_ERR_ARG, "auv_dataset_rows: every and refresh_every must be >= 1");
+    if (phase != 0 && phase != 1) return fail(h, AUV_ERR_ARG, "auv_dataset_rows: phase must be 0 or 1");
+    if (label_mode < ROWS_LABEL_NONE || label_mode > ROWS_LABEL_MEAN)
+        return fail(h, AUV_ERR_ARG, "auv_dataset_rows: unknown label mode %d", label_mode);
+    if (!due_count) return fail(h, AUV_ERR_ARG, "auv_dataset_rows: due_count is NULL");
+    if (phase == 1 && (!tracked || !row_of || !lidar_rows || !risk_rows || !meta_rows || !risk_len || !meta_len))
+        return fail(h, AUV_ERR_ARG, "auv_dataset_rows: null argument");
+    if (phase == 1 && label_mode != ROWS_LABEL_NONE && (!x_rows || !label))
+        return fail(h, AUV_ERR_ARG, "auv_dataset_rows: a label mode needs x_rows and label");
+    int rc = ready_to_run(h, true);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = pick(h, stream);
+    const Dims& d = h->d;
+    RowsArgs a;
+    a.V = d.V;
+    a.O = d.O;
+    a.R = d.R;
+    a.every = every;
+    a.refresh_every = refresh_every;
+    a.first = first ? 1 : 0;
+    a.sensor_range = h->cfg.sensor_range;
+    a.t_step = bp<int32_t>(h, AUV_BUF_T_STEP);
+    a.meta = bp<double>(h, AUV_BUF_META);
+    a.obst_dist = bp<double>(h, AUV_BUF_OBST_DIST);
+    a.risk = bp<double>(h, AUV_BUF_RISK);
+    a.own = bp<double>(h, AUV_BUF_OWN);
+    a.ranges = bp<double>(h, AUV_BUF_RANGES);
+    a.perception = bp<float>(h, AUV_BUF_PERCEPTION);
+    a.tracked = tracked;
+    a.row_of = reinterpret_cast<long long*>(row_of);
+    a.due_count = due_count;
+    a.lidar_rows = lidar_rows;
+    a.risk_rows = risk_rows;
+    a.meta_rows = meta_rows;
+    a.risk_len = risk_len;
+    a.meta_len = meta_len;
+    a.x_rows = label_mode != ROWS_LABEL_NONE ? x_rows : nullptr;
+    a.label = label_mode != ROWS_LABEL_NONE ? label : nullptr;
+    a.label_mode = label_mode;
+    if (phase == 0) {
+        HIP_TRY(h, hipMemsetAsync(due_count, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(k_rows_due, dim3((unsigned)((d.V + 255) / 256)), dim3(256), 0, st, a);
+    } else {
+        const unsigned blocks = (unsigned)((d.V + 3) / 4);
+        hipLaunchKernelGGL(k_rows_select, dim3(blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_fmt_scan, dim3(1), dim3(1024), 0, st, a.row_of, (long long)d.V);
+        hipLaunchKernelGGL(k_rows_write, dim3(blocks), dim3(256), 0, st, a);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return AUV_OK;
 }
 
 // ---- dataset text rows (host only) ------------------------------------------

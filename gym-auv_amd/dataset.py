@@ -267,10 +267,11 @@ def format_rows_device(values, row_len=None):
 class DeviceDatasetLogger:
     """`DatasetLogger` with the rows built and formatted on the GPU: the
     obstacle lists (`update_tracked`), the choice and compaction of the rows
-    and the "%.18e" text all stay on the device; the host receives the bytes of
-    the three files and writes them.  Same files, byte
-    for byte, as `DatasetLogger` writes from the same simulation.  `stream`:
-    the torch stream the simulation is stepped on (default: the current one)."""
+    (`auv_dataset_rows`) and the "%.18e" text (`auv_format_rows_device`) all
+    stay on the device; the host receives the bytes of the three files and
+    writes them.  Same files, byte for byte, as `DatasetLogger` writes from the
+    same simulation.  `stream`: the torch stream the simulation is stepped on
+    (default: the current one)."""
 
     def __init__(self, sim, writer: DatasetWriter | None, every: int = 5, refresh_every: int = 25,
                  collect: str | None = None):
@@ -278,17 +279,31 @@ class DeviceDatasetLogger:
         as a training sample, the scan as the network sees it and the label `calculate_total_risk` would form
         from the row's risk record; `samples()` returns what `load_lidar_dataset(..., mode=collect)` would
         read back from the files, without the files."""
+        import torch
+
         self.sim, self.writer, self.every, self.refresh_every = sim, writer, int(every), int(refresh_every)
         if writer is None and collect is None:
             raise ValueError("nothing to do: no writer and no samples to collect")
-        if collect not in (None, "max", "sum", "mean"):
+        if collect not in _lib.ROWS_LABEL:
             raise ValueError("collect must be None, 'max', 'sum' or 'mean'")
+        if self.every < 1 or self.refresh_every < 1:
+            raise ValueError("every and refresh_every must be >= 1")
         self.collect = collect
-        self._tracked = None
-        names = ("t_step", "meta", "obst_dist", "ranges", "own", "risk") + (("perception",) if collect else ())
-        self._buf = {k: sim.tensor(k) for k in names}
-        dev = self._buf["meta"].device.index
-        self._fmt = {k: DeviceRowFormatter(dev) for k in ("LiDAR", "risk", "metadata")}
+        self._lib = _lib.load()
+        V, R = sim.V, sim.R
+        O = int(sim.cfg["n_circles"]) + int(sim.cfg["n_polys"])
+        self._V, self._R, self._O = V, R, O
+        dev = torch.device("cuda", sim.device)
+        new = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        # the lists, and room for a row of every env (device memory: torch is the allocator here, nothing more)
+        self._tracked = torch.zeros((V, O), dtype=torch.uint8, device=dev)
+        self._row_of, self._due = new((V + 1,), torch.int64), torch.zeros(1, dtype=torch.int32, device=dev)
+        self._lidar, self._risk, self._meta = new((V, R), torch.float64), new((V, O), torch.float64), new((V, 2 + 5 * O), torch.float64)
+        self._risk_len, self._meta_len = new((V,), torch.int32), new((V,), torch.int32)
+        self._x = new((V, R), torch.float32) if collect else None
+        self._label = new((V,), torch.float32) if collect else None
+        self._first = True
+        self._fmt = {k: DeviceRowFormatter(sim.device) for k in ("LiDAR", "risk", "metadata")}
         self._X, self._y = [], []
         self.rows = 0
 
@@ -299,59 +314,39 @@ class DeviceDatasetLogger:
         if not self.collect:
             raise ValueError("this logger was not asked to collect samples")
         if not self._X:
-            R = self._buf["perception"].shape[-1]
-            dev = self._buf["perception"].device
-            return torch.empty((0, 1, R), dtype=torch.float32, device=dev), torch.empty((0, 1), dtype=torch.float32, device=dev)
+            dev = self._tracked.device
+            return (torch.empty((0, 1, self._R), dtype=torch.float32, device=dev),
+                    torch.empty((0, 1), dtype=torch.float32, device=dev))
         return torch.cat(self._X), torch.cat(self._y)
+
+    def _rows(self, phase, st):
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        rc = self._lib.auv_dataset_rows(self.sim._h, phase, self.every, self.refresh_every, 1 if self._first else 0,
+                                        _lib.ROWS_LABEL[self.collect], p(self._tracked), p(self._row_of), p(self._due),
+                                        p(self._lidar), p(self._risk), p(self._meta), p(self._risk_len), p(self._meta_len),
+                                        p(self._x), p(self._label), C.c_void_p(st.cuda_stream))
+        if rc != 0:
+            raise _lib.AuvError(rc, self._lib.auv_last_error(self.sim._h).decode())
 
     def after_step(self, stream=None):
         import torch
 
-        b = self._buf
-        st = torch.cuda.current_stream(b["meta"].device) if stream is None else stream
+        st = torch.cuda.current_stream(self._tracked.device) if stream is None else stream
         with torch.cuda.stream(st):
-            t = b["t_step"]
-            due = (t % self.every) == 0
-            if not bool(due.any()):
+            self._rows(0, st)
+            if int(self._due.item()) == 0:      # no env at a logging step: the lists stay as they are
                 return 0
-            meta = b["meta"]
-            present = torch.isfinite(b["obst_dist"])
-            fresh = present & (meta[:, :, 1] < float(self.sim.cfg["sensor_range"]))
-            if self._tracked is None:
-                self._tracked = fresh
-            else:
-                rebuild = (t % self.refresh_every) == 0
-                self._tracked = torch.where(rebuild[:, None], fresh, self._tracked & present)
-            trk = self._tracked & due[:, None]
-            idx = trk.any(dim=1).nonzero(as_tuple=False).squeeze(1)
-            n = int(idx.numel())
+            self._rows(1, st)
+            self._first = False
+            n = int(self._row_of[self._V].item())
             if n == 0:
                 return 0
-            everyone = n == trk.shape[0]
-            pick = (lambda x: x) if everyone else (lambda x: x[idx])
-            trk = pick(trk)
-            cnt = trk.sum(dim=1, dtype=torch.int32)
-            # the tracked obstacles of each sample to the front, id order kept
-            order = torch.argsort((~trk).to(torch.uint8), dim=1, stable=True)
-            risk_c = torch.gather(pick(b["risk"]), 1, order)
             if self.collect:
-                # the label of utils/dataloader.py:104-120: over at most 8 columns of the row's risk record
-                k = min(8, risk_c.shape[1])
-                head = risk_c[:, :k]
-                listed = torch.arange(k, device=head.device)[None, :] < cnt[:, None]
-                if self.collect == "max":
-                    y = torch.where(listed, head, head.new_full((), -float("inf"))).max(dim=1).values
-                else:
-                    y = torch.where(listed, head, head.new_zeros(())).sum(dim=1)
-                    if self.collect == "mean":
-                        y = y / torch.clamp(cnt, max=k).to(y.dtype)
-                self._X.append(pick(b["perception"]).reshape(n, 1, -1).clone())
-                self._y.append(y.to(torch.float32)[:, None])
+                self._X.append(self._x[:n].reshape(n, 1, self._R).clone())
+                self._y.append(self._label[:n, None].clone())
             if self.writer is not None:
-                meta_c = torch.gather(pick(meta), 1, order[:, :, None].expand(-1, -1, 5)).reshape(n, -1)
-                rows = {"LiDAR": (pick(b["ranges"]).reshape(n, -1).contiguous(), None),
-                        "risk": (risk_c.contiguous(), cnt),
-                        "metadata": (torch.cat([pick(b["own"]).reshape(n, 2), meta_c], dim=1), (2 + 5 * cnt).to(torch.int32))}
+                rows = {"LiDAR": (self._lidar[:n], None), "risk": (self._risk[:n], self._risk_len[:n]),
+                        "metadata": (self._meta[:n], self._meta_len[:n])}
                 tickets = {k: self._fmt[k].format(v, rl, st) for k, (v, rl) in rows.items()}
                 tails = torch.stack([self._fmt[k].tail(tickets[k]) for k in rows]).cpu()    # one read-back for the three
                 texts = {k: self._fmt[k].fetch(tickets[k], tails[i]) for i, k in enumerate(rows)}

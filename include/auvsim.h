@@ -311,6 +311,28 @@ int auv_episode_stats(auv_handle h, double* out, int32_t accumulate, void* strea
 #define AUV_STATS_MAX_ENVS 1048576
 int auv_episode_stats_static(auv_handle h, double* out, int32_t accumulate, void* stream);
 
+/* ---- dataset rows assembled on the device -------------------------------------
+ * What the reference's logger keeps per logged sample (the rows of LiDAR_*, risk_* and metadata_*.csv:
+ * utils/dataloader.py:55,59,108, utils/explore_dataset.py:8,40-53), from the batch's buffers, without the host:
+ * phase 0 counts the envs whose episode is at a multiple of `every` steps into due_count[0] (the obstacle
+ * lists are only touched on steps where some env is due: read it back, and stop there if it is 0);
+ * phase 1 brings every env's obstacle list up to date in `tracked` [V,O] u8 (rebuilt at multiples of
+ * `refresh_every` steps of the episode, or everywhere when `first` != 0, from the obstacles whose logged
+ * distance is below the sensor range; in between a list only loses obstacles whose slot went away), and
+ * writes one row per due env with a non-empty list, in env order: lidar_rows [n,R]; risk_rows [n,O] and
+ * meta_rows [n,2+5*O] with the listed obstacles first, id order kept; risk_len, meta_len [n]; row_of [V+1]
+ * i64 = the row of every env, row_of[V] = n.  With label_mode AUV_ROWS_LABEL_MAX / SUM / MEAN also the
+ * sample the reference's loader makes of the row (utils/dataloader.py:44-120): x_rows [n,R] f32 closeness
+ * and label [n] f32 over at most 8 of the row's risks.  All pointers are DEVICE memory sized for V rows.
+ * Feed the three row arrays to auv_format_rows_device for the files' text.  Asynchronous on `stream`. */
+#define AUV_ROWS_LABEL_NONE 0
+#define AUV_ROWS_LABEL_MAX 1
+#define AUV_ROWS_LABEL_SUM 2
+#define AUV_ROWS_LABEL_MEAN 3
+int auv_dataset_rows(auv_handle h, int32_t phase, int32_t every, int32_t refresh_every, int32_t first, int32_t label_mode,
+                     uint8_t* tracked, int64_t* row_of, int32_t* due_count, double* lidar_rows, double* risk_rows,
+                     double* meta_rows, int32_t* risk_len, int32_t* meta_len, float* x_rows, float* label, void* stream);
+
 /* ---- dataset text rows (host only, no GPU involved) -------------------------
  * Formats n_rows ragged rows of doubles as the reference's dataset files do
  * (numpy.savetxt defaults: "%.18e", single spaces, "\n"; the files read by
