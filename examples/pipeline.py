@@ -62,7 +62,8 @@ def run(envs=4096, steps=400, model="shallow", epochs=8, lr=2e-3, csv_dir=None, 
     tr, va, te = slice(0, n_train), slice(n_train, n_train + n_val), slice(len(X) - n_test, len(X))
     torch.manual_seed(2)
     net = MODELS[model]()
-    trainer = DeviceTrainer(net, epochs=epochs, learning_rate=lr, X_train=X[tr], y_train=y[tr], X_val=X[va], y_val=y[va])
+    trainer = DeviceTrainer(net, epochs=epochs, learning_rate=lr, X_train=X[tr], y_train=y[tr], X_val=X[va], y_val=y[va],
+                            optimizer="adam")   # the reference's own run (trainer.py:144-149)
     t0 = time.perf_counter()
     train_loss, val_loss = trainer.train()
     torch.cuda.synchronize()

@@ -117,21 +117,19 @@ __global__ __launch_bounds__(256) void k_rows_write(RowsArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
-            // the label of utils/dataloader.py:104-120 over the first 8 risks of the row, summed the way numpy
-            // sums a short vector: in order below 8 elements, as four pairs of pairs at 8
+            // the label of utils/dataloader.py:104-120 over the first 8 risks of the row.  Its sum is pandas'
+            // over 8 columns with zeros for the absent ones, which numpy adds as pairs of pairs
             const int k = n < 8 ? n : 8;
             const double* f = first8[w];
             double v;
             if (a.label_mode == ROWS_LABEL_MAX) {
                 v = f[0];
-                for (int i = 1; i < k; ++i) v = f[i] > v ? f[i] : v;
+                for (int i = 1; i < k; ++i) v = (f[i] > v || f[i] != f[i]) ? f[i] : v;  // a NaN wins, as in numpy's max
             } else {
-                if (k == 8) {
-                    v = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-                } else {
-                    v = f[0];
-                    for (int i = 1; i < k; ++i) v = v + f[i];
-                }
+                double g[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[i] = i < k ? f[i] : 0.0;
+                v = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
                 if (a.label_mode == ROWS_LABEL_MEAN) v = v / (double)k;
             }
             a.label[r] = (float)v;

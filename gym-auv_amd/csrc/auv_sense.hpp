@@ -7,14 +7,18 @@
 // k_sense    one workgroup per tile of envs, reading their scene ONCE from HBM:
 //   1. one thread per primitive (circle / polygon edge): (step only) advances
 //      the constant-velocity obstacle and writes it back; makes the primitive
-//      vessel-relative in LDS; derives its candidate ray interval
-//      (auv_lidar_raster.hpp) and appends its (primitive, ray) pairs to the
-//      tile's pair list; per edge also the distance to the vessel and the
-//      crossing-number bit;
-//   2. per obstacle, on three waves in parallel: signed hull distance,
-//      metadata, risk; per env: nearest obstacle, collision, reward, done;
-//   3. LiDAR, in the same barrier interval as 2: exact fp64 test of every
-//      listed pair, LDS atomic min per ray, then id resolution;
+//      vessel-relative in LDS; per edge also the squared distance to the vessel
+//      and the crossing-number bit.  Edges that a ray can reach (in range,
+//      facing the vessel) are listed per block of 64 edges, each block with a
+//      count of its own; there is no pair list and no shared counter;
+//   2. per obstacle, as two tasks on two waves: signed hull distance with the
+//      per-env summary (nearest obstacle, collision, reward, done); bearing,
+//      course, relative speed and risk;
+//   3. LiDAR, in the same barrier interval as 2, on the other waves: the circles
+//      and the listed edges are swept in units of 64 primitives; the unit's wave
+//      derives each primitive's candidate ray interval (auv_lidar_raster.hpp),
+//      deals the unit's (primitive, ray) pairs evenly over its lanes and runs
+//      the exact fp64 test of each; LDS atomic min per ray, then id resolution;
 //   4. 16 B per ray written out; with a network attached, its forward pass on
 //      the closeness values still in LDS.
 // Results are bit-identical to k_dynamics(advance) + k_encounter + k_lidar

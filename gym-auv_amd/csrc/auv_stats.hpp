@@ -32,18 +32,16 @@ struct StatsArgs {
     double* records;        // [blocks, kStatsFields]
 };
 
+// Minimum / maximum that a NaN wins, as torch's amin / amax and numpy's min / max have it: a NaN in the ranges
+// or the risks shows in the sums instead of being dropped by the comparison.
+__device__ __forceinline__ double nan_min(double v, double o) { return (o < v || o != o) ? o : v; }
+__device__ __forceinline__ double nan_max(double v, double o) { return (o > v || o != o) ? o : v; }
 __device__ __forceinline__ double wave_min(double v) {
-    for (int d = 32; d >= 1; d >>= 1) {
-        const double o = __shfl_xor(v, d, 64);
-        v = o < v ? o : v;
-    }
+    for (int d = 32; d >= 1; d >>= 1) v = nan_min(v, __shfl_xor(v, d, 64));
     return v;
 }
 __device__ __forceinline__ double wave_max(double v) {
-    for (int d = 32; d >= 1; d >>= 1) {
-        const double o = __shfl_xor(v, d, 64);
-        v = o > v ? o : v;
-    }
+    for (int d = 32; d >= 1; d >>= 1) v = nan_max(v, __shfl_xor(v, d, 64));
     return v;
 }
 
@@ -58,16 +56,14 @@ __global__ __launch_bounds__(kStatsThreads) void k_stats_partial(StatsArgs a) {
     for (int k = wave; k < kStatsEnvs; k += kStatsThreads / 64) {
         const int e = e0 + k;
         if (e >= a.V) break;  // wave-uniform
-        double lo = __builtin_inf(), hi = 0.0;
+        double lo = __builtin_inf(), hi = 0.0;  // risks are never negative
         const double* rg = a.ranges + (size_t)e * a.R;
         for (int r = lane; r < a.R; r += 64) {
-            const double t = rg[r];
-            lo = t < lo ? t : lo;
+            lo = nan_min(lo, rg[r]);
         }
         const double* rk = a.risk + (size_t)e * a.O;
         for (int o = lane; o < a.O; o += 64) {
-            const double t = rk[o];
-            hi = t > hi ? t : hi;
+            hi = nan_max(hi, rk[o]);
         }
         lo = wave_min(lo);
         hi = wave_max(hi);

@@ -106,6 +106,7 @@ struct auv_sim {
     double* stats_ws = nullptr;    // [stats_blocks(V), kStatsFields] records of k_stats_partial
     bool have_rays = false, have_scene = false, have_state = false;
     bool custom_rays = false;  // the ray table is not the evenly spaced full circle the rasterising path indexes by
+    bool mode_forced_by_rays = false;  // lidar_mode is ALL_PAIRS only because of such a table, not by the caller's choice
     int32_t scene_upto = 0;    // envs [0, scene_upto) have been uploaded (auv_set_scene sweeps front to back)
     // launch geometry
     int lidar_te = 1, lidar_block = 256, enc_eb = 1;
@@ -539,6 +540,15 @@ int upload_path(auv_sim* h, int32_t env_begin, int32_t env_count, const double* 
             const double* src = segments + (i * (size_t)ks + k) * 6;
             double* dst = &tab[(i * KS + k) * kPathRec];
             for (int f = 0; f < 6; ++f) dst[f] = src[f];
+            if (k < cnt[i]) {
+                // A vessel leaves a segment when its projection exceeds the segment's length: on a segment
+                // without length, or whose direction is not a unit vector, it would stay for ever.
+                const double uu = src[3] * src[3] + src[4] * src[4];
+                if (!(src[5] > 0.0) || !(std::fabs(uu - 1.0) <= 1e-9))
+                    return fail(h, AUV_ERR_ARG, "path of env %zu, segment %d: length %g and direction (%g, %g); a segment "
+                                "needs a length > 0 and (cos, sin) of its angle (drop repeated waypoints)",
+                                (size_t)env_begin + i, k, src[5], src[3], src[4]);
+            }
             dst[6] = cum;
             cum = cum + src[5];
         }
@@ -783,7 +793,14 @@ int auv_set_rays(auv_handle h, const double* ray_dirs) {
     HIP_TRY(h, hipMemcpy(h->ray_dirs, ray_dirs, (size_t)R * 2 * sizeof(double), hipMemcpyHostToDevice));
     h->have_rays = true;
     h->custom_rays = custom;
-    if (custom) h->lidar_mode = AUV_LIDAR_ALL_PAIRS;
+    if (custom && h->lidar_mode == AUV_LIDAR_RASTER) {
+        h->lidar_mode = AUV_LIDAR_ALL_PAIRS;
+        h->mode_forced_by_rays = true;
+    } else if (!custom && h->mode_forced_by_rays) {
+        // the standard table is back: so is the path the caller had before the custom one forced the other
+        if (h->raster_lds <= kLdsMax) h->lidar_mode = AUV_LIDAR_RASTER;
+        h->mode_forced_by_rays = false;
+    }
     return AUV_OK;
 }
 
@@ -1074,6 +1091,7 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
                 return fail(h, AUV_ERR_ARG, "auv_set_option: rasterising LiDAR needs %zu B of LDS per env (limit 163840)",
                             h->raster_lds);
             h->lidar_mode = value;
+            h->mode_forced_by_rays = false;  // the caller's own choice from here on
             return AUV_OK;
         case AUV_OPT_SENSE_BLOCK:
             if (value < 64 || value > 1024 || value % 64 != 0)
@@ -1084,7 +1102,10 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value) {
         case AUV_OPT_AUTO_RESET:
             if (value != 0 && value != 1) return fail(h, AUV_ERR_ARG, "auv_set_option: AUV_OPT_AUTO_RESET takes 0 or 1");
             if (value && h->lidar_mode != AUV_LIDAR_RASTER)
-                return fail(h, AUV_ERR_ARG, "auv_set_option: in-step restart needs the rasterising path");
+                return fail(h, AUV_ERR_ARG, "auv_set_option: in-step restart needs the rasterising path; this batch is on the "
+                            "all-pairs path because %s", h->custom_rays ? "its ray table (auv_set_rays) is not the evenly spaced "
+                            "full circle" : h->raster_lds > kLdsMax ? "one env's LDS image is too large for the rasterising kernel"
+                            : "AUV_OPT_LIDAR_MODE selected it");
             h->auto_reset = value;
             return AUV_OK;
         case AUV_OPT_META_EVERY:

@@ -389,16 +389,42 @@ def is_static(record, speed_os):
     return record[0] == 0 and record[2] == speed_os
 
 
+def reduce_risks(table, mode):
+    """Labels of a table of per-obstacle risks [n, <= 8 columns], NaN = no such
+    obstacle: 'max', 'sum', else the mean over the obstacles a row holds
+    (utils/dataloader.py:110-117).  The reference forms the sum with pandas,
+    which fills the absent columns with zeros and adds the 8 columns of a row
+    as pairs of pairs; the same order here, so that the float64 labels are the
+    reference's bit for bit (adding in file order differs in the last place
+    for about a seventh of the rows that hold 4 to 7 risks)."""
+    table = np.asarray(table, dtype=np.float64)
+    have = ~np.isnan(table)
+    if mode == "max":
+        return np.where(have, table, -np.inf).max(axis=1)
+    f = np.zeros((len(table), 8))
+    f[:, :table.shape[1]] = np.where(have, table, 0.0)
+    total = ((f[:, 0] + f[:, 1]) + (f[:, 2] + f[:, 3])) + ((f[:, 4] + f[:, 5]) + (f[:, 6] + f[:, 7]))
+    return total if mode == "sum" else total / have.sum(axis=1)
+
+
+def risk_table(rows):
+    """Ragged risk rows as the 8-column table, NaN-filled, that the reference's
+    `read_csv(..., names=range(8))` makes of them (utils/dataloader.py:108)."""
+    out = np.full((len(rows), 8), np.nan)
+    for i, r in enumerate(rows):
+        out[i, :min(len(r), 8)] = r[:8]
+    return out
+
+
 def calculate_total_risk(path_y, mode):
     """Label per sample from its per-obstacle risks: 'max', 'sum', else the
     mean, over at most 8 columns, absent columns skipped
-    (utils/dataloader.py:104-120)."""
-    rows = read_ragged(path_y)
-    out = np.empty(len(rows))
-    for i, r in enumerate(rows):
-        r = r[:8]
-        out[i] = r.max() if mode == "max" else r.sum() if mode == "sum" else r.mean()
-    return out
+    (utils/dataloader.py:104-120).  The text is read correctly rounded; the
+    reference's pandas parser is up to one unit in the last place off on a
+    quarter of the values, so its float64 labels can differ from these in the
+    last place (none of the shipped rows' labels differs as float32, which is
+    what the networks are given)."""
+    return reduce_risks(risk_table(read_ragged(path_y)), mode)
 
 
 def prev_timesteps_feature_engineering(X, time_steps):
@@ -430,11 +456,10 @@ def _binary_rows(npz_path, mode):
     order = np.argsort(~tracked, axis=1, kind="stable")
     risk_c = np.take_along_axis(risk, order, axis=1)
     cnt = tracked.sum(axis=1)
-    y = np.empty(len(ranges))
-    for i in range(len(ranges)):
-        r = risk_c[i, :min(cnt[i], 8)]
-        y[i] = r.max() if mode == "max" else r.sum() if mode == "sum" else r.mean()
-    return ranges, y
+    table = np.full((len(ranges), 8), np.nan)
+    w = min(8, risk_c.shape[1])
+    table[:, :w] = np.where(np.arange(w)[None, :] < cnt[:, None], risk_c[:, :w], np.nan)
+    return ranges, reduce_risks(table, mode)
 
 
 def load_lidar_dataset(path_x, path_y=None, mode=None, train_test_split=0.7, train_val_split=0.2):

@@ -16,9 +16,14 @@ def _conv(cin, cout, k, stride, pad):
 
 
 class LidarCNNShallow(nn.Module):
-    def __init__(self):
+    """One circular convolution over three 15-ray sectors at a time, then a
+    12 -> 1 linear layer.  The defaults are the shipped configuration
+    (trainer.py:127-130); like the reference's class, the linear layer takes 12
+    inputs whatever the arguments."""
+
+    def __init__(self, channels=(1,), kernel_size=45, padding=15, stride=15):
         super().__init__()
-        self.feature_extractor = nn.Sequential(_conv(1, 1, 45, 15, 15), nn.ReLU(), nn.Flatten())
+        self.feature_extractor = nn.Sequential(_conv(1, channels[0], kernel_size, stride, padding), nn.ReLU(), nn.Flatten())
         self.linear = nn.Sequential(nn.Linear(12, 1), nn.ReLU())
 
     def forward(self, x):
@@ -26,10 +31,14 @@ class LidarCNNShallow(nn.Module):
 
 
 class LidarCNN2Deep(nn.Module):
-    def __init__(self):
+    """channels [3,2,1]: the shipped configuration (trainer.py:137-140); the
+    kernels, strides and paddings are fixed, as in the reference's class."""
+
+    def __init__(self, channels=(3, 2, 1)):
         super().__init__()
+        c0, c1, c2 = channels
         self.feature_extractor = nn.Sequential(
-            _conv(1, 3, 45, 15, 15), nn.ReLU(), _conv(3, 2, 3, 1, 1), nn.ReLU(), _conv(2, 1, 3, 1, 1), nn.Flatten())
+            _conv(1, c0, 45, 15, 15), nn.ReLU(), _conv(c0, c1, 3, 1, 1), nn.ReLU(), _conv(c1, c2, 3, 1, 1), nn.Flatten())
         self.linear_1 = nn.Sequential(nn.Linear(12, 1), nn.ReLU())
 
     def forward(self, x):
@@ -39,14 +48,15 @@ class LidarCNN2Deep(nn.Module):
 class LidarCNNDeep(nn.Module):
     """channels [2,4,4,6], kernel 9: the configuration of the shipped weights (trainer.py:144)."""
 
-    def __init__(self, channels=(2, 4, 4, 6), kernel_size=9):
+    def __init__(self, channels=(2, 4, 4, 6), kernel_size=9, n_sensors=180):
         super().__init__()
         layers, cin, pad = [], 1, (kernel_size - 1) // 2
         for c in channels:
             layers += [_conv(cin, c, kernel_size, 1, pad), nn.ReLU(), nn.MaxPool1d(2, 2, ceil_mode=True)]
             cin = c
         self.feature_extractor = nn.Sequential(*layers, nn.Flatten())
-        self.linear_1 = nn.Sequential(nn.Linear(12 * channels[-1], 40), nn.ReLU(), nn.Linear(40, 8))
+        pooled = -(-n_sensors // 2 ** len(channels))     # every pool halves, rounding up
+        self.linear_1 = nn.Sequential(nn.Linear(pooled * channels[-1], 40), nn.ReLU(), nn.Linear(40, 8))
         self.linear_2 = nn.Sequential(nn.ReLU(), nn.Linear(8, 1), nn.ReLU())
 
     def forward(self, x):

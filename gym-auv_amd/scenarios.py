@@ -57,7 +57,10 @@ def waypoint_path(points, n_points=None):
     """Segment records [V,K-1,6] = (x0, y0, angle, cos, sin, length) of the
     polylines through `points` [V,K,2] (what `AuvSim.set_path` and the oracles'
     `set_path` take), and the number of segments in use per env ([V]; from
-    `n_points` [V] waypoints in use, default all K)."""
+    `n_points` [V] waypoints in use, default all K).  Waypoints in use must
+    differ from their successors (a segment without length is refused at
+    upload) and should turn by less than 90 degrees (a vessel leaves a segment
+    when its projection passes the segment's end)."""
     pts = np.asarray(points, dtype=np.float64)
     d = pts[:, 1:] - pts[:, :-1]
     length = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1])

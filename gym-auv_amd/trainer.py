@@ -9,16 +9,18 @@ import torch.nn as nn
 
 
 class Trainer:
-    def __init__(self, model: nn.Module, epochs: int, learning_rate: float, optimizer: str = "adamw",
+    def __init__(self, model: nn.Module, epochs: int, learning_rate: float, optimizer: str = "sgd",
                  device: str = "cpu"):
+        """optimizer: 'adam' (or 'adamw') is AdamW, anything else SGD with momentum 0.9, and SGD is
+        the default: the choice of the reference's constructor (trainer.py:25,35-38)."""
         self.model = model.to(device)
         self.device = device
         self.epochs = int(epochs)
         self.loss = nn.MSELoss()
-        if optimizer == "sgd":
-            self.optimizer = torch.optim.SGD(self.model.parameters(), lr=learning_rate, momentum=0.9)
-        else:
+        if optimizer in ("adam", "adamw"):
             self.optimizer = torch.optim.AdamW(self.model.parameters(), lr=learning_rate)
+        else:
+            self.optimizer = torch.optim.SGD(self.model.parameters(), lr=learning_rate, momentum=0.9)
         self.training_loss, self.validation_loss = [], []
 
     def train_batch(self, X, y):
@@ -63,7 +65,7 @@ class DeviceTrainer:
     before."""
 
     def __init__(self, model, epochs: int, learning_rate: float, X_train, y_train, X_val=None, y_val=None,
-                 optimizer: str = "adamw", batch_size: int = 16, seed: int = 2, device: int = 0):
+                 optimizer: str = "sgd", batch_size: int = 16, seed: int = 2, device: int = 0):
         import ctypes as C
 
         from . import _lib
@@ -73,7 +75,7 @@ class DeviceTrainer:
         self._lib, self._C, self._api = _lib.load(), C, _lib
         if not 1 <= batch_size <= _lib.TRAIN_BATCH_MAX:
             raise ValueError(f"batch_size must be in 1..{_lib.TRAIN_BATCH_MAX}")
-        kinds = [k for k, cls in MODELS.items() if type(model) is cls]
+        kinds = [k for k, cls in MODELS.items() if isinstance(model, cls)]   # subclasses: compat's reference-named ones
         if not kinds:
             raise TypeError(f"DeviceTrainer trains {', '.join(c.__name__ for c in MODELS.values())}; got {type(model).__name__}")
         self.kind = kinds[0]
@@ -95,7 +97,7 @@ class DeviceTrainer:
                              f"{self._lib.auv_cnn_n_weights(self._kind_id)} (default channels and kernel only)")
         self.w = torch.from_numpy(packed).to(dev)
         self.opt_state = torch.zeros(2 * self.w.numel(), dtype=torch.float32, device=dev)
-        self.hp = _lib.AuvTrainParams(optimizer=_lib.OPT_SGD_MOMENTUM if optimizer == "sgd" else _lib.OPT_ADAMW,
+        self.hp = _lib.AuvTrainParams(optimizer=_lib.OPT_ADAMW if optimizer in ("adam", "adamw") else _lib.OPT_SGD_MOMENTUM,
                                       reserved=0, lr=float(learning_rate), beta1=0.9, beta2=0.999, eps=1e-8,
                                       weight_decay=0.01, momentum=0.9)
         self.steps_done = 0
@@ -141,7 +143,10 @@ class DeviceTrainer:
         return self.model
 
     @torch.no_grad()
-    def validation_step(self):
+    def validation_step(self, perm=None):
+        """`perm`: the order in which a shuffling validation loader hands out the
+        rows (which rows its dropped partial batch leaves out depends on it);
+        default: file order."""
         if self.Xv is None or len(self.Xv) == 0:
             return float("nan")
         from .cnn import LidarCNN
@@ -149,11 +154,16 @@ class DeviceTrainer:
         net = LidarCNN(self.kind, self.sync_model().state_dict(), device=self.device)
         pred = net.forward(self.Xv.reshape(-1, 1, 180), "risk")[:, 0]
         net.close()
-        # the reference averages the losses of the validation batches (trainer.py:55-69)
+        # the reference averages the losses of the validation batches (trainer.py:55-69), and its validation
+        # loader drops the last partial batch (utils/dataloader.py:86-90): full batches only
         b = self.batch_size
         per = (pred - self.yv) ** 2
-        means = [per[i:i + b].mean() for i in range(0, len(per), b)]
-        return float(torch.stack(means).mean().item())
+        if perm is not None:
+            per = per[torch.as_tensor(perm).to(per.device)]
+        n_full = len(per) // b
+        if n_full == 0:
+            return float("nan")
+        return float(per[:n_full * b].reshape(n_full, b).mean(dim=1).mean().item())
 
     def train(self):
         for _ in range(self.epochs):

@@ -171,7 +171,9 @@ void auv_destroy(auv_handle h);
  * the reference's 180-ray scan is pinned to, to +-2 rays, by its logged rows
  * and shipped networks); a table that differs from it by more than 1e-9
  * switches the batch to AUV_LIDAR_ALL_PAIRS, which reads the directions only,
- * and AUV_LIDAR_RASTER is then refused by auv_set_option. */
+ * and AUV_LIDAR_RASTER is then refused by auv_set_option.  Uploading the
+ * standard table again puts a batch that was switched this way back on
+ * AUV_LIDAR_RASTER; a path selected through AUV_OPT_LIDAR_MODE is left alone. */
 int auv_set_rays(auv_handle h, const double* ray_dirs);
 
 /* Upload scene data for envs [env_begin, env_begin+env_count), front to back

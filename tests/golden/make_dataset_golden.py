@@ -5,7 +5,8 @@ own loader code.  Runs only where /root/reference is mounted.
       data/risk_MovingObstaclesNoRules.csv and data/metadata_MovingObstaclesNoRules.csv
       (data files, copied verbatim: they pin the text format and the ragged layout)
   dataset_golden.npz                  what the reference's utils/dataloader.py computes on
-      those rows: calculate_total_risk(mode) for max / sum / mean (:104-120),
+      those rows: calculate_total_risk(mode) for max / sum / mean (:104-120) and the table pandas
+      parses those rows into (the call of :108),
       prev_timesteps_feature_enginering (:123-134) on a small scan array, and the
       split sizes of load_LiDARDataset (:63-67) for the full 10,075-row set.
 
@@ -37,6 +38,20 @@ def main():
     risk_path = os.path.join(HERE, "risk_rows.csv")
     for mode in ("max", "sum", "mean"):
         out[f"label_{mode}"] = D.calculate_total_risk(risk_path, mode)
+    # the table those labels were reduced from, as the reference's read_csv call (:108) parses the text: pandas'
+    # default number parser is not correctly rounded (a quarter of the values are one unit in the last place
+    # off), so the float64 labels above follow from THIS table, bit for bit, not from the text read exactly
+    import pandas as pd
+
+    out["risk_parsed"] = pd.read_csv(risk_path, delimiter=r"\s+", header=None, names=list(range(8))).to_numpy()
+    # the rows of the whole shipped file that hold 4 or more risks (1,887 of 10,075; the first 300 rows hold at
+    # most 3, where the order of addition cannot show): table as parsed, and the reference's labels of them
+    full = os.path.join(REF, "data", "risk_MovingObstaclesNoRules.csv")
+    table = pd.read_csv(full, delimiter=r"\s+", header=None, names=list(range(8))).to_numpy()
+    many = np.flatnonzero((~np.isnan(table)).sum(axis=1) >= 4)
+    out["many_rows"], out["many_parsed"] = many, table[many]
+    for mode in ("max", "sum", "mean"):
+        out[f"many_label_{mode}"] = D.calculate_total_risk(full, mode)[many]
     X = np.random.default_rng(0).uniform(0, 150, (7, D.N_SENSORS))
     out["prev_in"] = X
     out["prev_out"] = D.prev_timesteps_feature_enginering(X, 3)

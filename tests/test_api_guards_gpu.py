@@ -47,8 +47,19 @@ def test_custom_ray_table_takes_the_all_pairs_path_and_matches_the_oracle(table)
             got = sim.read(name)
             assert same_bits(got, np.asarray(getattr(env, attr)).reshape(got.shape)), (name, k)
     assert (env.hit >= 0).any()
-    # the standard table again: the rasterising path is available again
+    with pytest.raises(_lib.AuvError, match="ray table"):      # the refusal names its cause
+        sim.set_option(_lib.OPT_AUTO_RESET, 1)
+    # the standard table again: the batch is back on the rasterising path by itself (the custom table had forced
+    # the other one, the caller had not chosen it), so the in-step restart is accepted again
     sim.set_rays(params.ray_table(R))
+    sim.set_option(_lib.OPT_AUTO_RESET, 1)
+    sim.set_option(_lib.OPT_AUTO_RESET, 0)
+    # an all-pairs path chosen by the caller stays chosen whatever table is uploaded
+    sim.set_option(_lib.OPT_LIDAR_MODE, _lib.LIDAR_ALL_PAIRS)
+    sim.set_rays(rays)
+    sim.set_rays(params.ray_table(R))
+    with pytest.raises(_lib.AuvError, match="AUV_OPT_LIDAR_MODE selected it"):
+        sim.set_option(_lib.OPT_AUTO_RESET, 1)
     sim.set_option(_lib.OPT_LIDAR_MODE, _lib.LIDAR_RASTER)
     sim.close()
 
@@ -154,3 +165,32 @@ def test_a_rollout_can_be_captured_into_a_graph_and_replays_bit_for_bit():
     assert int(got["plain"]["t_step"].max()) < K           # restarts happened
     for k, v in got["plain"].items():
         assert np.array_equal(v, got["graph"][k], equal_nan=True), k
+
+
+def test_paths_with_a_repeated_waypoint_or_a_bad_direction_are_refused():
+    """A vessel leaves a segment when its projection exceeds the segment's length; a segment of length 0 (repeated
+    waypoint) or without a unit direction would hold it for ever, so the upload refuses both.  Slots beyond the
+    segments in use are not looked at."""
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=8)
+    cfg["n_path_segments"] = 3
+    sim = AuvSim(cfg)
+    sim.set_scene(scene)
+    pts = np.zeros((8, 4, 2))
+    pts[:, 1] = (100.0, 0.0)
+    pts[:, 2] = (200.0, 50.0)
+    pts[:, 3] = (300.0, 50.0)
+    seg, n = scenarios.waypoint_path(pts)
+    sim.set_path(seg, n)
+    twice = pts.copy()
+    twice[5, 2] = twice[5, 1]                      # env 5 names a waypoint twice
+    seg2, n2 = scenarios.waypoint_path(twice)
+    with pytest.raises(_lib.AuvError, match=r"env 5, segment 1: length 0"):
+        sim.set_path(seg2, n2)
+    n_short = n2.copy()
+    n_short[5] = 1                                 # ... but uses only the first segment: fine
+    sim.set_path(seg2, n_short)
+    bad = seg.copy()
+    bad[2, 0, 3:5] = (0.6, 0.6)                    # not (cos, sin) of an angle
+    with pytest.raises(_lib.AuvError, match=r"env 2, segment 0"):
+        sim.set_path(bad, n)
+    sim.close()

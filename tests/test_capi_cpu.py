@@ -34,6 +34,45 @@ def test_config_struct_layout_matches_header():
     assert C.sizeof(_lib.AuvConfig) == 8 * 4 + (7 + 3 + 4 + 16) * 8
 
 
+def _header_config_fields():
+    """(name, C type, array length or 0) of every member of `auv_config`, in order, from the header text."""
+    text = open(os.path.join(ROOT, "include", "auvsim.h")).read()
+    body = re.search(r"typedef struct auv_config\s*\{(.*?)\}\s*auv_config;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        m = re.match(r"\s*(int32_t|double)\s+(.*)$", decl.strip(), flags=re.S)
+        if not m:
+            continue
+        for item in m.group(2).split(","):
+            a = re.match(r"\s*(\w+)\s*(?:\[(\w+)\])?\s*$", item)
+            n = a.group(2) or "0"
+            if not n.isdigit():      # a length given by a #define of the header
+                n = re.search(r"#define\s+%s\s+(\d+)" % n, text).group(1)
+            out.append((a.group(1), m.group(1), int(n)))
+    return out
+
+
+def test_binding_and_integration_stub_name_the_headers_config_fields():
+    """The struct in the ctypes binding and the one INTEGRATION.md shows a maintainer must both be the header's:
+    same member names, types and array lengths, in the same order."""
+    want = _header_config_fields()
+    assert len(want) == 18 and want[7] == ("n_path_segments", "int32_t", 0)
+    ctype = {"int32_t": C.c_int32, "double": C.c_double}
+    got = []
+    for name, t in _lib.AuvConfig._fields_:
+        n = getattr(t, "_length_", 0)
+        got.append((name, {C.c_int32: "int32_t", C.c_double: "double"}[t._type_ if n else t], n))
+    assert got == want
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class auv_config(ctypes.Structure)"):]
+    stub = stub[:stub.index("]\n") + 1]
+    fields = re.findall(r'\("(\w+)",\s*ctypes\.(c_int32|c_double)(?:\s*\*\s*(\d+))?\)', stub)
+    shown = [(n, {"c_int32": "int32_t", "c_double": "double"}[t], int(k or 0)) for n, t, k in fields]
+    assert shown == want, "INTEGRATION.md's auv_config stub differs from include/auvsim.h"
+    assert ctype  # (both maps above cover every type the header uses)
+
+
 def test_buffer_enum_matches_header():
     text = open(os.path.join(ROOT, "include", "auvsim.h")).read()
     enum = dict(re.findall(r"(AUV_BUF_[A-Z_]+)\s*=\s*(\d+)", text))

@@ -52,7 +52,23 @@ def test_metadata_rows_are_aligned_with_risk_rows():
 @pytest.mark.parametrize("mode", ["max", "sum", "mean"])
 def test_risk_reduction_matches_reference_loader(gold, mode):
     y = D.calculate_total_risk(os.path.join(G, "risk_rows.csv"), mode)
+    # the text read exactly against the reference's pandas parse of it: a unit or two in the last place, none as float32
     assert np.allclose(y, gold[f"label_{mode}"], rtol=1e-15, atol=0)
+    assert np.array_equal(y.astype(np.float32), gold[f"label_{mode}"].astype(np.float32))
+    # the reduction itself, on the table the reference reduced (its own parse of the rows): bit for bit, which
+    # for sum and mean needs pandas' order of addition (8 zero-filled columns as pairs of pairs)
+    assert np.array_equal(D.reduce_risks(gold["risk_parsed"], mode), gold[f"label_{mode}"])
+    # ... and on the 1,887 rows of the whole shipped file that hold 4 to 8 risks, where the order shows
+    many = gold["many_parsed"]
+    assert len(many) == 1887 and np.array_equal(D.reduce_risks(many, mode), gold[f"many_label_{mode}"])
+    if mode != "max":
+        t = np.nan_to_num(many, nan=0.0)
+        in_order = t[:, 0].copy()
+        for j in range(1, 8):
+            in_order = in_order + t[:, j]
+        if mode == "mean":
+            in_order = in_order / (~np.isnan(many)).sum(axis=1)
+        assert (in_order != gold[f"many_label_{mode}"]).sum() > 200     # adding in file order misses these
 
 
 def test_prev_timesteps_and_split_match_reference(gold):

@@ -69,3 +69,28 @@ def test_episode_stats_argument_checks():
     with pytest.raises(TypeError):
         sim.episode_stats(torch.zeros(7, dtype=torch.float64, device="cuda"))
     sim.close()
+
+
+def test_a_nan_in_the_ranges_or_the_risks_shows_in_the_sums():
+    """torch's amin / amax hand a NaN on, and so does the device reduction: a NaN planted in one env's risks and in
+    another env's ranges makes both sums NaN on both paths, and nothing else."""
+    import torch
+
+    cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=200)
+    sim = make_sim(cfg, scene)
+    sim.reset(scene["init_state"])
+    dev = torch.device("cuda")
+    clean = torch.zeros(8, dtype=torch.float64, device=dev)
+    sim.episode_stats(clean)
+    assert bool(torch.isfinite(clean).all())
+    sim.tensor("risk")[77, 3] = float("nan")
+    sim.tensor("ranges")[131, 179] = float("nan")
+    got = torch.zeros(8, dtype=torch.float64, device=dev)
+    sim.episode_stats(got)
+    ref = D.EpisodeStats(dev)
+    ref.update(sim.tensor("done"), sim.tensor("collision"), sim.tensor("reached_goal"), sim.tensor("truncated"),
+               sim.tensor("reward"), ranges=sim.tensor("ranges"), risk=sim.tensor("risk"))
+    assert torch.equal(torch.isnan(got), torch.isnan(ref.vec))
+    assert torch.isnan(got).tolist() == [False] * 6 + [True, True]
+    assert torch.equal(got[:6], clean[:6])
+    sim.close()

@@ -122,3 +122,56 @@ def test_training_on_the_reference_rows_reaches_the_published_error(kind, col, e
     print(kind, "test MSE of the network trained here:", mse, "published band", lo, hi, "train/val loss per epoch:",
           train_loss, val_loss)
     assert lo < mse < hi, mse
+
+
+def test_validation_loss_averages_full_batches_only():
+    """The reference's validation loader drops the last partial batch (utils/dataloader.py:86-90) and its trainer
+    averages the batch losses (trainer.py:55-69): 37 validation rows at batch 16 are two batches, the last 5 rows
+    play no part; fewer rows than a batch give no loss at all."""
+    X, y = _data(48, 3)
+    Xv, yv = _data(37, 4)
+    model = MODELS["shallow"]()
+    t = T.DeviceTrainer(model, 1, 1e-3, X, y, Xv, yv, optimizer="sgd", batch_size=16)
+    got = t.validation_step()
+    with torch.no_grad():
+        per = ((model(torch.from_numpy(Xv)) - torch.from_numpy(yv)) ** 2)[:, 0]
+    want = float(torch.stack([per[0:16].mean(), per[16:32].mean()]).mean())
+    assert abs(got - want) <= 1e-6
+    assert abs(got - float(per.mean())) > 1e-6 or float(per[32:].abs().max()) == 0.0   # not the plain mean
+    few = T.DeviceTrainer(model, 1, 1e-3, X, y, Xv[:10], yv[:10], batch_size=16)
+    assert np.isnan(few.validation_step())
+    # the defaults are the reference constructor's: SGD with momentum unless 'adam' is asked for (trainer.py:25,35-38)
+    from gym_auv_amd import _lib
+    assert few.hp.optimizer == _lib.OPT_SGD_MOMENTUM
+    assert T.DeviceTrainer(model, 1, 1e-3, X, y, optimizer="adam").hp.optimizer == _lib.OPT_ADAMW
+
+
+@pytest.mark.parametrize("kind,optimizer,lr", [("deep2", "adam", 1e-3), ("shallow", "sgd", 1e-2), ("deep", "adam", 1e-3)])
+def test_compat_trainer_on_the_gpu_sees_the_batches_of_the_reference_loop(kind, optimizer, lr):
+    """`compat.Trainer` (the reference's constructor, trainer.py:18-41) with shuffling loaders: on the GPU it trains
+    on the very batches, and validates on the very rows, that the eager loop draws from the loaders under the same
+    seed, so losses and parameters agree to the tolerance of the fused kernel."""
+    from gym_auv_amd import compat
+
+    X, y = _data(83, 1)
+    Xv, yv = _data(40, 2)
+    start = _live_model(kind, X, y)
+
+    def run(device):
+        model = MODELS[kind]()
+        model.load_state_dict(start.state_dict())
+        sets = [compat.LiDARDataset(X[:, 0], y[:, 0]), compat.LiDARDataset(Xv[:, 0], yv[:, 0])]
+        tr, va = (torch.utils.data.DataLoader(d, batch_size=16, shuffle=True, drop_last=True) for d in sets)
+        torch.manual_seed(5)
+        t = compat.Trainer(model, 3, lr, tr, va, optimizer=optimizer, device=device)
+        t.train()
+        return t, model
+
+    cpu, m_cpu = run("cpu")
+    gpu, m_gpu = run("cuda")
+    assert gpu.on_device and not cpu.on_device
+    assert np.abs(np.array(gpu.training_loss) - np.array(cpu.training_loss)).max() <= TOL
+    assert np.abs(np.array(gpu.validation_loss) - np.array(cpu.validation_loss)).max() <= TOL
+    for k, v in m_cpu.state_dict().items():
+        assert np.abs(m_gpu.state_dict()[k].numpy() - v.numpy()).max() <= TOL, k
+    assert cpu.training_loss[-1] < cpu.training_loss[0]
