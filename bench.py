@@ -8,7 +8,9 @@ over one batch of synthetic envs, actions already resident in HBM.  The default
 workload is cfg3: 65,536 vessels per GPU, 8 circles + 8 moving 5-edge ships per
 env, 180 rays.  With N > 1 every rank steps its own 65,536 envs (weak scaling,
 no data-path collective); the episode-statistic vector is all-reduced once per
-rollout inside the timed region.  Rank 0 prints ONE JSON line.  `--gpus N` run
+rollout inside the timed region, and after the timed rollouts every rank's last
+scans are gathered on the trainer rank 0 (timed on its own and reported as
+`scan_gather`, not part of `value`).  Rank 0 prints ONE JSON line.  `--gpus N` run
 as a plain `python bench.py` starts its N ranks itself (torch.distributed.run,
 one rank per GPU, rendezvous on 127.0.0.1) before anything touches a GPU; run
 under torch.distributed.run it takes the ranks it is given, and refuses a
@@ -183,13 +185,23 @@ def rehearse_without_gpu(args, world, rank):
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # the scan gather of the multi-rank line, on stand-in scans (64 envs per rank, each rank's filled with its number)
+    mine = torch.full((64, 1, 180), float(rank + 1))
+    gathered = torch.empty((64 * world, 1, 180)) if rank == 0 else None
+    t1 = time.perf_counter()
+    auv_dist.gather_scans(mine, dst=0, out=gathered)
+    g_ms = (time.perf_counter() - t1) * 1e3
+    ok = None if rank else bool(torch.equal(gathered[:, 0, 0].reshape(world, 64)[:, 0], torch.arange(1.0, world + 1.0)))
     if rank == 0:
         print(json.dumps({"metric": "vessel_env_steps_per_sec", "value": 0.0, "unit": "env-steps/s", "n_gpus": world,
                           "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f64", "data": "rehearsal without a GPU: no simulation ran",
                           "config": {"workload": args.workload or "cfg4_8x65536_moving",
                                      "sharding": f"envs x{world}, no data-path collective"},
-                          "ranks_joined": int(totals["env_steps"])}), flush=True)
+                          "ranks_joined": int(totals["env_steps"]),
+                          "collectives": {"backend": "gloo", "stats_allreduce_ms": float(t[0]) * 1e3,
+                                          "scan_gather": {"ms": g_ms, "bytes_inbound": 64.0 * 180 * 4 * (world - 1),
+                                                          "checked": ok}}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -213,8 +225,9 @@ def main():
                     help="LiDAR CNN fed zero-copy with every step's scans (features head)")
     ap.add_argument("--cnn-mode", default="attached", choices=["attached", "separate"],
                     help="attached: evaluated inside the sensing kernel; separate: its own launch per step")
-    ap.add_argument("--spin-seconds", type=float, default=1.0,
-                    help="untimed stepping that brings a cold GPU to its working clocks before the warm-up "
+    ap.add_argument("--spin-seconds", type=float, default=5.0,
+                    help="upper bound of the untimed stepping that brings a cold GPU to its working clocks before the "
+                         "warm-up: blocks of 50 steps until two consecutive blocks agree within 2 %% "
                          "(0 under a profiler, so that its per-kernel averages cover the measured rollout only)")
     ap.add_argument("--no-auto-reset", action="store_true",
                     help="leave finished episodes (collided / arrived / truncated envs) as they are instead of "
@@ -228,8 +241,9 @@ def main():
                     help="after the timed rollouts, regenerate dataset rows (LiDAR / risk / metadata text files) "
                          "from the running batch for 25 steps and report rows/s; auto: for the dense cfg5 workload, "
                          "whose purpose that is")
-    ap.add_argument("--gather-scans", action="store_true",
-                    help="also gather the final scans of every rank on rank 0 once per rollout")
+    ap.add_argument("--gather-scans", default="auto", choices=["auto", "on", "off"],
+                    help="gather the last scans of every rank on the trainer rank 0 after the timed rollouts and "
+                         "report its time and rate (auto: whenever there is a process group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="threads of the CPU baseline (0 = the CPUs this process may use, at most 16)")
@@ -271,13 +285,19 @@ def main():
     rehearse = os.environ.get("AUV_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
-    if world > 1:
+    # AUV_BENCH_FORCE_GROUP=1: create the process group on a single rank too, so that a one-GPU box runs the very
+    # collectives (RCCL initialisation, barrier, statistics all-reduce, scan gather) of the multi-GPU run
+    grouped = world > 1 or os.environ.get("AUV_BENCH_FORCE_GROUP") == "1"
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if world > 1 and dist.get_world_size() != args.gpus:
+    if grouped and dist.get_world_size() != args.gpus:
         sys.exit(3)   # fewer ranks joined than asked for
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -330,19 +350,15 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if grouped:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
     def episode_stats():
-        # episode statistics of a rollout: one small all-reduce (RCCL), not per step;
-        # optionally the last scans of every rank gathered on the trainer rank 0
+        # episode statistics of a rollout: one small all-reduce (RCCL), not per step
         st = auv_dist.EpisodeStats(dev)
         st.update_from_sim(sim, stream=stream)
-        totals = st.reduce()
-        if args.gather_scans and per_all is not None:
-            auv_dist.gather_scans(per_all, dst=0)
-        return totals
+        return st.reduce()
 
     def rollout():
         for k in range(args.steps):
@@ -351,19 +367,34 @@ def main():
                 net.forward(per_t, "features", out=feats)
         return episode_stats()
 
-    # bring a cold GPU to its working clocks first (a fresh process on an idle
-    # box runs its first second about 2x slow), then the W warm-up steps
+    # bring a cold GPU to its working clocks first, then the W warm-up steps (a fresh process on an idle
+    # box runs its first second about 2x slow and keeps ramping for a while): blocks of 50 steps, each from the
+    # reset state so that they do the same work, until two consecutive blocks agree within 2 %
     t_spin = time.perf_counter()
+    spin_blocks = []
     while time.perf_counter() - t_spin < args.spin_seconds:
+        sim.reset(scene["init_state"], stream=stream)
+        torch.cuda.synchronize(dev)
+        tb = time.perf_counter()
         for k in range(50):
             sim.step_device(ptrs[k % n_act], stream=stream)
             if net is not None:
                 net.forward(per_t, "features", out=feats)
         torch.cuda.synchronize(dev)
+        spin_blocks.append((time.perf_counter() - tb) / 50 * 1e3)
+        if len(spin_blocks) >= 4 and abs(spin_blocks[-1] - spin_blocks[-2]) <= 0.02 * spin_blocks[-2] \
+                and abs(spin_blocks[-1] - spin_blocks[-3]) <= 0.02 * spin_blocks[-3]:
+            break
+    spin_s = time.perf_counter() - t_spin
     def prepare():
-        # a measured rollout starts from the reset state (whatever came before did
-        # to the episodes) and runs the W warm-up steps: both passes see the same scene
-        sim.reset(scene["init_state"], stream=stream)
+        # A measured rollout starts from the reset state (whatever came before did to the episodes) and runs the W
+        # warm-up steps: every pass sees the same scene.  Before it, untimed, as many steps again as the rollout
+        # has (150 at least): the reset of a short rollout would otherwise follow a host-side pause long enough
+        # for the clocks to drop.  The reset takes the initial states already on the device, so nothing here
+        # waits for the host.
+        for k in range(max(150, args.steps) if args.spin_seconds > 0 else 0):
+            sim.step_device(ptrs[k % n_act], stream=stream)
+        sim.reset(None, stream=stream)
         for k in range(args.warmup):
             sim.step_device(ptrs[k % n_act], stream=stream)
 
@@ -377,6 +408,49 @@ def main():
         stats = rollout()
         sync_all()
         times.append(time.perf_counter() - t0)
+
+    # the two collectives on their own: the statistics all-reduce (which the timed region above contains) and the
+    # gather of every rank's last scans on the trainer rank 0; barrier-bracketed like the rollouts, 5 repeats each
+    collectives = None
+    want_gather = args.gather_scans == "on" or (args.gather_scans == "auto" and grouped)
+    if grouped or want_gather:
+        def timed(fn, reps=5):
+            out = []
+            for _ in range(reps):
+                sync_all()
+                t0 = time.perf_counter()
+                fn()
+                sync_all()
+                out.append(time.perf_counter() - t0)
+            tt = torch.tensor(out, device=dev, dtype=torch.float64)
+            auv_dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return sorted(tt.tolist())[reps // 2] * 1e3
+
+        sync_ms = timed(lambda: None)            # what the bracket itself costs
+        collectives = {"stats_allreduce_ms": timed(episode_stats), "bracket_ms": sync_ms}
+        if want_gather:
+            gathered = torch.empty((V * world, 1, R), dtype=torch.float32, device=dev) if rank == 0 else None
+            auv_dist.gather_scans(per_all, dst=0, out=gathered)     # first call: connections set up
+            g_ms = timed(lambda: auv_dist.gather_scans(per_all, dst=0, out=gathered))
+            # every rank's checksum against the slice the trainer holds
+            # (the bit patterns added as integers: exact, whatever the order of the addition)
+            sums = torch.zeros(world, dtype=torch.int64, device=dev)
+            sums[rank] = per_all.view(torch.int32).sum(dtype=torch.int64)
+            auv_dist.all_reduce(sums)
+            ok = None
+            if rank == 0:
+                ok = bool(torch.equal(gathered.view(torch.int32).reshape(world, -1).sum(dim=1, dtype=torch.int64), sums)) \
+                    and bool(torch.equal(gathered[:V], per_all))
+            inbound = float(V) * R * 4 * (world - 1)
+            collectives["scan_gather"] = {
+                "ms": g_ms, "bytes_inbound": inbound, "bytes_per_rank": float(V) * R * 4,
+                "GB/s": inbound / max(g_ms - sync_ms, 1e-6) / 1e6,
+                "frac_of_7x153": inbound / max(g_ms - sync_ms, 1e-6) / 1e6 / (7 * 153.0),
+                "checked": ok,
+                "what": "every rank's last scans [V,1,R] float32 to the trainer rank 0 (dist.gather_scans: peer-to-peer "
+                        "gather into the slices of one tensor), median of 5, barrier-bracketed; the rate is over the "
+                        "time less the bracket's own, against the trainer's 7 inbound xGMI links x 153 GB/s"}
+            del gathered
 
     # second pass, instrumented: HIP events around every kernel, on the launch stream
     prepare()
@@ -472,7 +546,13 @@ def main():
             "kernel_ms": ({"k_vessel": vessel_s * 1e3, "k_sense": sense_s * 1e3} if fused else
                           {"k_dynamics": vessel_s * 1e3, "k_encounter": enc_s * 1e3, "k_lidar": sense_s * 1e3}),
             "episode_stats": stats,
+            "ranks_joined": dist.get_world_size() if grouped else 1,
+            "spin": {"seconds": spin_s, "ms_per_step_blocks": spin_blocks,
+                     "rule": "blocks of 50 steps from the reset state until the last block is within 2 % of each of "
+                             f"the two before it, {args.spin_seconds:g} s at most"},
         }
+        if collectives is not None:
+            out["collectives"] = dict(collectives, backend=dist.get_backend())
         if dataset_rate is not None:
             out["dataset_regeneration"] = dataset_rate
         if cnn_ms is not None:
@@ -492,6 +572,8 @@ def main():
             out["roofline"] = {
                 "kernel": "k_sense", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs / HBM_PEAK_GBS, "traffic": measured_traffic(tkey, "k_sense"),
+                "traffic_source": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 PMC "
+                                  "passes over this workload (profiles/traffic.json), not counted in this run",
                 "bytes_per_launch": nbytes,
                 "avg_launch_ms": sense_s * 1e3,
                 "note": "rasterised LiDAR + encounter + obstacle advance in one pass over the scene; "
@@ -528,7 +610,7 @@ def main():
                                                args.cpu_scalar_envs)
         print(json.dumps(out), flush=True)
     sim.close()
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

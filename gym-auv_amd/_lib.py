@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AUVSIM_LIB points diagnostic runs at another build of the same library
 LIB_PATH = os.environ.get("AUVSIM_LIB") or os.path.join(_HERE, "libauvsim.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 N_MODEL = 16
 
 # auv_dtype
@@ -70,7 +70,7 @@ class AuvConfig(C.Structure):
         ("dt", C.c_double), ("sensor_range", C.c_double), ("vessel_radius", C.c_double),
         ("thrust_max", C.c_double), ("moment_max", C.c_double), ("look_ahead", C.c_double),
         ("goal_radius", C.c_double), ("risk", C.c_double * 3), ("reward", C.c_double * 4),
-        ("model", C.c_double * N_MODEL),
+        ("model", C.c_double * N_MODEL), ("contact_dist", C.c_double),
     ]
 
 

@@ -290,6 +290,7 @@ struct EncArgs {
     double* reward;
     float* navigation;  // [V,1,6]
     double sensor_range, vessel_radius, look_ahead, goal_radius;
+    double contact_dist;
     double w_d, w_c, t_c;
     double rw_progress, rw_collision, rw_goal, rw_cte;
     int max_steps;
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256) void k_encounter(EncArgs a) {
                 bi = o;
             }
         }
-        const uint8_t coll = best < 0.0 ? 1 : 0;
+        const uint8_t coll = best < a.contact_dist ? 1 : 0;
         a.min_dist[e] = best;
         a.min_idx[e] = bi;
         a.collision[e] = coll;

@@ -187,6 +187,7 @@ struct SenseArgs {
     int32_t* min_idx;
     double* reward;
     double dt, sensor_range, vessel_radius;
+    double contact_dist;  // collision <=> nearest obstacle distance below this
     double inv_range;  // 1 / sensor_range, rounded to nearest
     double w_d, w_c, t_c;
     double rw_collision, rw_goal;
@@ -328,7 +329,7 @@ __device__ __forceinline__ double risk_index(double mx, double my, double rvx, d
 
 // per-env outputs that need the scene: nearest obstacle, collision, reward, done
 __device__ __forceinline__ void env_summary(const SenseArgs& a, int e, double bd, int bi) {
-    const uint8_t coll = bd < 0.0 ? 1 : 0;
+    const uint8_t coll = bd < a.contact_dist ? 1 : 0;
     const uint8_t goal = a.reached_goal[e];
     a.min_dist[e] = bd;
     a.min_idx[e] = bi;

@@ -388,6 +388,7 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.sensor_range = h->cfg.sensor_range;
     sa.inv_range = 1.0 / h->cfg.sensor_range;
     sa.vessel_radius = h->cfg.vessel_radius;
+    sa.contact_dist = h->cfg.contact_dist;
     sa.w_d = h->cfg.risk[0];
     sa.w_c = h->cfg.risk[1];
     sa.t_c = h->cfg.risk[2];
@@ -457,6 +458,7 @@ int launch_sense(auv_sim* h, hipStream_t st, hipEvent_t* ev, int is_step) {
     ea.navigation = bp<float>(h, AUV_BUF_NAVIGATION);
     ea.sensor_range = h->cfg.sensor_range;
     ea.vessel_radius = h->cfg.vessel_radius;
+    ea.contact_dist = h->cfg.contact_dist;
     ea.look_ahead = h->cfg.look_ahead;
     ea.goal_radius = h->cfg.goal_radius;
     ea.w_d = h->cfg.risk[0];
@@ -632,7 +634,9 @@ int do_step(auv_sim* h, const double* action_dev, hipStream_t st) {
 
 extern "C" {
 
-const char* auv_version(void) { return "libauvsim abi 2 gfx950 fp64-unfused"; }
+#define AUV_STR2(x) #x
+#define AUV_STR(x) AUV_STR2(x)
+const char* auv_version(void) { return "libauvsim abi " AUV_STR(AUVSIM_ABI_VERSION) " gfx950 fp64-unfused"; }
 
 const char* auv_last_error(auv_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -653,6 +657,8 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
         return fail(nullptr, AUV_ERR_ARG, "auv_create: n_path_segments must be in 0..4096");
     if (!(cfg->dt > 0.0) || !(cfg->sensor_range > 0.0))
         return fail(nullptr, AUV_ERR_ARG, "auv_create: dt and sensor_range must be positive");
+    if (cfg->contact_dist != cfg->contact_dist)
+        return fail(nullptr, AUV_ERR_ARG, "auv_create: contact_dist is NaN");
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev <= 0)
@@ -947,8 +953,9 @@ int auv_reset(auv_handle h, const uint8_t* mask, const double* init_state, void*
     h->have_state = true;
     rc = launch_sense(h, st, nullptr, 0);
     if (rc) return rc;
-    // the staging copies read caller memory: finish before returning
-    HIP_TRY(h, hipStreamSynchronize(st));
+    // the staging copies read caller memory: finish before returning (a reset from the states already on the
+    // device reads none and stays asynchronous, like a step)
+    if (init_state || mask) HIP_TRY(h, hipStreamSynchronize(st));
     return AUV_OK;
 }
 

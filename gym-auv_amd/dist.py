@@ -62,11 +62,13 @@ class EpisodeStats:
 
 
 def all_reduce(t: torch.Tensor, op=dist.ReduceOp.SUM, group=None) -> torch.Tensor:
-    """In-place all-reduce of a small tensor.  RCCL reduces device tensors in
+    """In-place all-reduce of a small tensor (a no-op without a process group;
+    with one, the collective runs whatever the group's size, also on a single
+    rank).  RCCL reduces device tensors in
     place; a gloo group (CPU tests, the one-GPU rehearsal of the multi-rank
     path) gets a host copy, because gloo's handling of device tensors stalls
     when several ranks share one GPU."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return t
     if t.is_cuda and dist.get_backend(group) == "gloo":
         host = t.cpu()
@@ -89,8 +91,8 @@ def gather_scans(perception: torch.Tensor, dst: int = 0, group=None, out: torch.
     slices of ONE result tensor (`out`, or a new one): no padding, no
     concatenation, nothing copied twice on the trainer.  Shards that differ in
     size by an env are padded to the longest for the collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return perception
+    if not (dist.is_available() and dist.is_initialized()):
+        return perception if out is None else out.copy_(perception)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     sizes = torch.zeros(world, dtype=torch.int64)

@@ -59,13 +59,21 @@ def ray_table(n_rays: int = N_RAYS_DEFAULT) -> np.ndarray:
     return np.ascontiguousarray(np.stack([np.cos(ang), np.sin(ang)], axis=1))
 
 
+# Collision <=> the nearest obstacle's logged-style distance (hull distance less the 3.255 m the reference takes off
+# every distance) falls below this: the hull within 1.255 m of the vessel's centre.  The reference's log rules out
+# 0 (contact at 3.255 m): its vessel passed ships at hull distances down to 2.53 m in episodes that went on
+# (tests/test_ref_contact_cpu.py).
+CONTACT_DIST_DEFAULT = -2.0
+
+
 def make_config(n_envs: int, n_circles: int, n_polys: int, n_verts: int = 5,
                 n_rays: int = N_RAYS_DEFAULT, dt: float = 1.0,
                 sensor_range: float = SENSOR_RANGE_DEFAULT,
                 vessel_radius: float = 3.255, thrust_max: float = 2.0,
                 moment_max: float = 0.075, look_ahead: float = 100.0,
                 goal_radius: float = 5.0, max_steps: int = 10000,
-                risk=(0.4, 0.6, 60.0), reward=(1.0, 100.0, 100.0, 0.01)) -> dict:
+                risk=(0.4, 0.6, 60.0), reward=(1.0, 100.0, 100.0, 0.01),
+                contact_dist: float = CONTACT_DIST_DEFAULT) -> dict:
     """Plain dict understood by `AuvSim` (device) and by the CPU oracle."""
     return {
         "n_envs": int(n_envs), "n_rays": int(n_rays), "n_circles": int(n_circles),
@@ -75,5 +83,5 @@ def make_config(n_envs: int, n_circles: int, n_polys: int, n_verts: int = 5,
         "look_ahead": float(look_ahead), "goal_radius": float(goal_radius),
         "max_steps": int(max_steps), "risk": tuple(float(x) for x in risk),
         "reward": tuple(float(x) for x in reward),
-        "model": model_constants(),
+        "model": model_constants(), "contact_dist": float(contact_dist),
     }

@@ -8,7 +8,7 @@ import weakref
 
 import numpy as np
 
-from . import _lib, dlpack
+from . import _lib, dlpack, params
 from .params import ray_table
 
 _NP_DTYPE = {_lib.F64: np.float64, _lib.F32: np.float32, _lib.I32: np.int32, _lib.U8: np.uint8,
@@ -61,6 +61,7 @@ class AuvSim:
         for k in ("dt", "sensor_range", "vessel_radius", "thrust_max", "moment_max",
                   "look_ahead", "goal_radius"):
             setattr(c, k, float(cfg[k]))
+        c.contact_dist = float(cfg.get("contact_dist", params.CONTACT_DIST_DEFAULT))
         c.risk[:] = [float(x) for x in cfg["risk"]]
         c.reward[:] = [float(x) for x in cfg["reward"]]
         model = np.asarray(cfg["model"], dtype=np.float64)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define AUVSIM_ABI_VERSION 2   /* 2: auv_scene_params.size_law */
+#define AUVSIM_ABI_VERSION 3   /* 2: auv_scene_params.size_law; 3: auv_config.contact_dist */
 #define AUV_N_MODEL 16
 #define AUV_NAV_FEATURES 6   /* radarCNN.py:185 */
 #define AUV_META_FIELDS 5    /* utils/explore_dataset.py:45 */
@@ -73,6 +73,11 @@ typedef struct auv_config {
                                   reserved (0), Xu, Xuu, Yv, Yvv, Yr, Nv, Nr, Nrr (damping, positive):
                                   nu' = Minv (tau - [(Xu+Xuu|u|)u, (Yv+Yvv|v|)v + (m u + Yr) r,
                                   Nv v + (m x_g u + Nr + Nrr|r|) r]) */
+    double contact_dist;    /* collision <=> the nearest obstacle's distance (AUV_BUF_MIN_DIST: hull distance less
+                               vessel_radius) is below this.  Default -2.0: the hull within 1.255 m of the vessel's
+                               centre.  0 (contact at vessel_radius itself) is contradicted by the reference's log,
+                               whose vessel passed ships at hull distances down to 2.53 m in episodes that went on
+                               (data/metadata_MovingObstaclesNoRules.csv rows 7362-7366, counting from 0) */
 } auv_config;
 
 typedef enum auv_dtype { AUV_F64 = 0, AUV_F32 = 1, AUV_I32 = 2, AUV_U8 = 3, AUV_I64 = 4 } auv_dtype;

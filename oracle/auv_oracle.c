@@ -56,6 +56,7 @@ typedef struct {
     int32_t risk_model, KS;     /* 0: closest-point-of-approach index, 1: oc_risk_reference; KS: segment slots per path */
     double dt, sensor_range, vessel_radius, thrust_max, moment_max, look_ahead, goal_radius;
     double risk[3], reward[4], model[16];
+    double contact_dist;        /* collision <=> nearest obstacle distance below this */
 } oc_config;
 
 typedef struct {
@@ -374,7 +375,7 @@ static void oc_sense_env(const oc_config *cf, const oc_buffers *b, int e, int is
         if (dist[o] < md) { md = dist[o]; mi = o; }
     b->min_dist[e] = md;
     b->min_idx[e] = mi;
-    const uint8_t coll = md < 0.0;
+    const uint8_t coll = md < cf->contact_dist;
     b->collision[e] = coll;
 
     /* metadata and risk */

@@ -341,11 +341,12 @@ def lidar(state, circles, poly_pose, poly_verts, poly_nv, ray_dirs, sensor_range
 # ----------------------------------------------------------------------------
 # a4: signed obstacle distances and the collision predicate
 # ----------------------------------------------------------------------------
-def obstacle_distances(state, circles, poly_pose, poly_verts, poly_nv, vessel_radius):
+def obstacle_distances(state, circles, poly_pose, poly_verts, poly_nv, vessel_radius, contact_dist=-2.0):
     """Signed hull distance per obstacle: (centre-to-surface distance, negative
     inside the obstacle) minus vessel_radius.  Absent obstacles give +inf.
     Returns (dist [V,C+P], collision u8 [V], min_dist [V], min_idx i32 [V]);
-    collision <=> some dist < 0; min_idx = lowest id attaining the minimum
+    collision <=> some dist < contact_dist (-2 with the default 3.255 m radius: the hull
+    within 1.255 m of the vessel's centre); min_idx = lowest id attaining the minimum
     (-1 when the env has no obstacle)."""
     V = state.shape[1]
     C = circles.shape[1]
@@ -398,7 +399,7 @@ def obstacle_distances(state, circles, poly_pose, poly_verts, poly_nv, vessel_ra
     else:
         min_idx = np.full(V, -1, dtype=np.int32)
         min_dist = np.full(V, np.inf)
-    collision = (min_dist < 0.0).astype(np.uint8)
+    collision = (min_dist < contact_dist).astype(np.uint8)
     return dist, collision, min_dist, min_idx
 
 
@@ -668,7 +669,7 @@ class OracleEnv:
         (self.obst_dist, self.collision, self.min_dist,
          self.min_idx) = obstacle_distances(self.state, self.circles, self.poly_pose,
                                             self.poly_verts, self.poly_nv,
-                                            cfg["vessel_radius"])
+                                            cfg["vessel_radius"], float(cfg.get("contact_dist", -2.0)))
         self.own, self.meta = encounter_metadata(self.state, self.circles, self.poly_pose,
                                                  self.poly_heading, self.obst_dist)
         if int(cfg.get("risk_model", 1)) == 1:

@@ -22,7 +22,7 @@ class OcConfig(C.Structure):
                 ("dt", C.c_double), ("sensor_range", C.c_double), ("vessel_radius", C.c_double),
                 ("thrust_max", C.c_double), ("moment_max", C.c_double), ("look_ahead", C.c_double),
                 ("goal_radius", C.c_double), ("risk", C.c_double * 3), ("reward", C.c_double * 4),
-                ("model", C.c_double * 16)]
+                ("model", C.c_double * 16), ("contact_dist", C.c_double)]
 
 
 _BUFS = ("state", "t_step", "circles", "poly_pose", "poly_verts", "poly_heading", "path", "ray_dirs", "poly_nv",
@@ -69,6 +69,7 @@ class COracleEnv:
         c.risk[:] = [float(x) for x in cfg["risk"]]
         c.reward[:] = [float(x) for x in cfg["reward"]]
         c.model[:] = [float(x) for x in cfg["model"]]
+        c.contact_dist = float(cfg.get("contact_dist", -2.0))
         self._c = c
         self.threads = max(1, int(threads))
         self._pool = ThreadPoolExecutor(self.threads) if self.threads > 1 else None

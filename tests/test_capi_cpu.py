@@ -30,8 +30,8 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_config_struct_layout_matches_header():
-    # 8 int32 + 7 double + risk[3] + reward[4] + model[16]
-    assert C.sizeof(_lib.AuvConfig) == 8 * 4 + (7 + 3 + 4 + 16) * 8
+    # 8 int32 + 7 double + risk[3] + reward[4] + model[16] + contact_dist
+    assert C.sizeof(_lib.AuvConfig) == 8 * 4 + (7 + 3 + 4 + 16 + 1) * 8
 
 
 def _header_config_fields():
@@ -57,7 +57,7 @@ def test_binding_and_integration_stub_name_the_headers_config_fields():
     """The struct in the ctypes binding and the one INTEGRATION.md shows a maintainer must both be the header's:
     same member names, types and array lengths, in the same order."""
     want = _header_config_fields()
-    assert len(want) == 18 and want[7] == ("n_path_segments", "int32_t", 0)
+    assert len(want) == 19 and want[7] == ("n_path_segments", "int32_t", 0)
     ctype = {"int32_t": C.c_int32, "double": C.c_double}
     got = []
     for name, t in _lib.AuvConfig._fields_:

@@ -189,6 +189,10 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_joined"] == 2 and out["config"]["sharding"].startswith("envs x2")
+    # a multi-rank line carries the two collectives of the 8-GPU configuration without being asked for them: the
+    # statistics all-reduce and the gather of every rank's scans on the trainer rank, checked against their senders
+    assert out["collectives"]["stats_allreduce_ms"] > 0
+    assert out["collectives"]["scan_gather"]["checked"] is True and out["collectives"]["scan_gather"]["bytes_inbound"] > 0
     # a rank count that differs from --gpus is refused, not silently measured
     env2 = dict(env, WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
