@@ -382,7 +382,8 @@ def main():
                 net.forward(per_t, "features", out=feats)
         torch.cuda.synchronize(dev)
         spin_blocks.append((time.perf_counter() - tb) / 50 * 1e3)
-        if len(spin_blocks) >= 4 and abs(spin_blocks[-1] - spin_blocks[-2]) <= 0.02 * spin_blocks[-2] \
+        if time.perf_counter() - t_spin >= min(0.3, args.spin_seconds) and len(spin_blocks) >= 4 \
+                and abs(spin_blocks[-1] - spin_blocks[-2]) <= 0.02 * spin_blocks[-2] \
                 and abs(spin_blocks[-1] - spin_blocks[-3]) <= 0.02 * spin_blocks[-3]:
             break
     spin_s = time.perf_counter() - t_spin
@@ -547,9 +548,9 @@ def main():
                           {"k_dynamics": vessel_s * 1e3, "k_encounter": enc_s * 1e3, "k_lidar": sense_s * 1e3}),
             "episode_stats": stats,
             "ranks_joined": dist.get_world_size() if grouped else 1,
-            "spin": {"seconds": spin_s, "ms_per_step_blocks": spin_blocks,
-                     "rule": "blocks of 50 steps from the reset state until the last block is within 2 % of each of "
-                             f"the two before it, {args.spin_seconds:g} s at most"},
+            "spin": {"seconds": spin_s, "blocks": len(spin_blocks), "ms_per_step_blocks": spin_blocks[:4] + spin_blocks[-4:],
+                     "rule": "blocks of 50 steps from the reset state, for 0.3 s at least and until the last block is "
+                             f"within 2 % of each of the two before it, {args.spin_seconds:g} s at most"},
         }
         if collectives is not None:
             out["collectives"] = dict(collectives, backend=dist.get_backend())

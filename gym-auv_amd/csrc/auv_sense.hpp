@@ -353,7 +353,7 @@ __device__ long long* g_stamps = nullptr;
 #define AUV_STAMP(n)                                                                                  \
     do {                                                                                              \
         if (g_stamps && (threadIdx.x & 63) == 0)                                                      \
-            g_stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (n)] = __builtin_amdgcn_s_memtime(); \
+            g_stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (n)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define AUV_STAMP(n)

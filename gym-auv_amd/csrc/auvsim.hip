@@ -1191,7 +1191,16 @@ int auv_debug_violations(int64_t* out) {
 #endif
 
 #ifdef AUV_PHASE_STAMPS
-// diagnostic builds only: device buffer [blocks*4*16] of i64 that k_sense stamps
+// diagnostic builds only: the launch shape of the sensing kernel {envs per workgroup, threads, LDS bytes, 0}
+int auv_debug_geometry(auv_handle h, int32_t* out) {
+    if (!h || !out) return AUV_ERR_ARG;
+    out[0] = h->raster_te;
+    out[1] = h->sense_block;
+    out[2] = (int32_t)h->raster_lds;
+    out[3] = 0;
+    return AUV_OK;
+}
+// diagnostic builds only: device buffer [blocks * waves per block * 16] of i64 that k_sense stamps
 int auv_debug_set_stamps(void* p) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof p) == hipSuccess ? AUV_OK : AUV_ERR_DEVICE;
 }
