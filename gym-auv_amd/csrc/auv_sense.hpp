@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
 struct SenseArgs {
     Dims d;
     int TE;       // envs per workgroup
-    int lds[10];  // byte offsets of the LDS arrays (sense_layout, computed once on the host): env, circ, seg,
-                  // best, obst, edist, ids, ecross, live, wsum
+    int lds[11];  // byte offsets of the LDS arrays (sense_layout, computed once on the host): env, circ, seg,
+                  // best, obst, edist, ids, ecross, live, wsum, queue
     int is_step;  // 1: advance obstacles, finish the reward; 0: after reset / plain sense
     int with_meta;  // 0: bearing, course and risk of the obstacles are not refreshed by this pass
     int refresh_heading;  // 0: the heading_ts column (a constant of the scene) is rewritten only for restarting envs
@@ -199,7 +199,7 @@ struct SenseArgs {
 };
 
 struct SenseLayout {
-    size_t env, circ, seg, best, obst, edist, ids, ecross, live, wsum, total;  // byte offsets
+    size_t env, circ, seg, best, obst, edist, ids, ecross, live, wsum, queue, total;  // byte offsets
 };
 
 // LDS image per tile (f64 blocks first, then words and bytes).
@@ -208,12 +208,21 @@ struct SenseLayout {
 //                      (field-major: the lanes of a wave walk the banks)
 //   edist[TE*S] f64    ids[TE*R]   ecross[TE*S]   live[TE*S] numbers of the edges that have candidate rays,
 //   by blocks of 64 edges   wsum[blocks] how many each block lists
+//   queue (general shape only): the two counters the waves draw their work items from, then a byte per item
 // With a network evaluated in-kernel (cnn_kind >= 0) its input (R floats per env)
 // and its weights reuse the bytes of obst[], and its two activation buffers
 // per env those of best[], both dead by then; the regions are padded when
 // they are smaller than that.
 // packed: the narrow image of the compile-time shape (DefaultShape): edges without their stored cross
 // product, 8-bit crossing records and edge numbers.
+// The sweep parts a unit's rounds are dealt into at most, and the work items of a tile at most: two tasks per
+// round of 64 obstacles, and that many parts per unit of 64 circles or 64 edges.
+constexpr int kShareMax = 4;
+__host__ __device__ inline size_t sense_max_items(int TE, int C, int P, int NV) {
+    const size_t rounds = ((size_t)TE * (C + P) + 63) / 64, units = ((size_t)TE * C + 63) / 64 + ((size_t)TE * P * NV + 63) / 64;
+    return 2 * (rounds ? rounds : 1) + units * kShareMax;
+}
+
 __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P, int NV, int cnn_kind, bool packed = false) {
     SenseLayout L;
     const size_t S = (size_t)P * NV, O = (size_t)C + P;
@@ -232,6 +241,8 @@ __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P,
     L.live = o; o += (size_t)TE * S * (packed ? 1 : 2);
     o = (o + 3) & ~(size_t)3;
     L.wsum = o; o += (((size_t)TE * S + 63) / 64 + 1) * 4;
+    L.queue = o;
+    if (!packed) o += 8 + ((sense_max_items(TE, C, P, NV) + 3) & ~(size_t)3);
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
@@ -408,13 +419,13 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     const int NV = FIXED ? DefaultShape::NV : a.d.NV, O = FIXED ? DefaultShape::C + DefaultShape::P : a.d.O;
     const int S = P * NV;
     const int TE = FIXED ? DefaultShape::TE : a.TE;
-    struct { int env, circ, seg, best, obst, edist, ids, ecross, live, wsum; } L = {
-        a.lds[0], a.lds[1], a.lds[2], a.lds[3], a.lds[4], a.lds[5], a.lds[6], a.lds[7], a.lds[8], a.lds[9]};
+    struct { int env, circ, seg, best, obst, edist, ids, ecross, live, wsum, queue; } L = {
+        a.lds[0], a.lds[1], a.lds[2], a.lds[3], a.lds[4], a.lds[5], a.lds[6], a.lds[7], a.lds[8], a.lds[9], a.lds[10]};
     if (FIXED) {
         // constants but for the room an attached network takes in front of best[]
         const SenseLayout T = sense_layout(TE, R, C, P, NV, a.cnn_w ? a.cnn_kind : -1, true);
         L = {(int)T.env, (int)T.circ, (int)T.seg, (int)T.best, (int)T.obst, (int)T.edist, (int)T.ids, (int)T.ecross,
-             (int)T.live, (int)T.wsum};
+             (int)T.live, (int)T.wsum, (int)T.queue};
     }
     double* env = reinterpret_cast<double*>(lds_raw + L.env);
     double* circ = reinterpret_cast<double*>(lds_raw + L.circ);
@@ -444,6 +455,8 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         return FIXED ? (int)(lds_raw + L.live)[idx] : (int)reinterpret_cast<const unsigned short*>(lds_raw + L.live)[idx];
     };
     int* wsum = reinterpret_cast<int*>(lds_raw + L.wsum);
+    int* queue = reinterpret_cast<int*>(lds_raw + L.queue);                 // (general shape) two counters,
+    unsigned char* item_flag = lds_raw + L.queue + 8;                        // then a byte per work item
     const int e0 = blockIdx.x * TE;
     const int ne = min(TE, V - e0);
     const int n_circ = ne * C;
@@ -471,6 +484,10 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         env_c = er[ER_COS];
         env_s = er[ER_SIN];
         env_psi = a.state[2 * (size_t)V + e0 + tid];
+    }
+    if (!FIXED && tid == 0) {
+        queue[0] = nthr >> 6;  // every wave's first item is its own number: the draws start behind those
+        queue[1] = nthr >> 6;
     }
     const unsigned long long range_bits = (unsigned long long)__double_as_longlong(range);
     for (int f = tid; f < ne * R; f += nthr) {
@@ -634,15 +651,33 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     // in lane order and shares them out evenly: pair j goes to lane j % 64, which
     // finds the primitive by bisection over the running counts.  So the time goes
     // with the number of pairs, not with the widest primitive.
+    //
+    // Work items of the interval.  In the compile-time shape the tasks of phase 2
+    // have the first waves and the sweep's units the others.  In the general
+    // shape the waves draw items from a counter in LDS as they become free:
+    // first the jobs of phase 2 (task x round of 64 obstacles), then the sweep's
+    // (unit, part) pairs, so that a dense scene's obstacle rounds and a long
+    // unit's rounds spread over the whole workgroup whatever their sizes.
     const int n_tasks = a.with_meta ? 2 : 1;
-    const int first_ray_wave = n_waves > n_tasks ? n_tasks : 0;
-    const int n_ray_waves = n_waves - first_ray_wave;
+    const int n_rounds = FIXED ? 1 : max(1, (ne * O + 63) >> 6);
+    const int n_jobs = n_tasks * n_rounds;
     const int n_blocks = (ne * S + 63) >> 6;
     int n_live = 0;
     for (int b = 0; b < n_blocks; ++b) n_live += wsum[b];
     const int units_c = (n_circ + 63) >> 6, n_units = units_c + ((n_live + 63) >> 6);
-    // with waves to spare, several open the same unit and deal its rounds among them
-    const int n_share = (FIXED || n_units == 0 || n_ray_waves < 2 * n_units) ? 1 : n_ray_waves / n_units;
+    // A unit's rounds are dealt into n_share parts, each an item of its own (its wave opens the unit again): more
+    // parts the more rays a primitive can cover, and at least enough for every wave to find one.
+    const int by_rays = (R + 179) / 180, by_waves = n_units > 0 ? n_waves / n_units : 1;
+    const int n_share = (FIXED || n_units == 0) ? 1 : min(kShareMax, max(1, max(by_rays, by_waves)));
+    const int n_items = n_jobs + n_units * n_share;
+    AUV_CHECK(FIXED || n_items <= (int)sense_max_items(TE, C, P, NV));
+    // the next item off counter `which`, the same in every lane; items >= n_items: the list has run out
+    auto draw = [&](int which, int base) -> int {
+        int it = 0;
+        if (lane == 0) it = atomicAdd(&queue[which], 1);
+        return base + __builtin_amdgcn_readfirstlane(it);
+    };
+    const int first_ray_wave = n_tasks, n_ray_waves = n_waves - n_tasks;  // (compile-time shape only)
     struct Unit {
         int incl, excl, total;      // running count of pairs up to and with this lane's primitive, without it; all
         unsigned int desc, desc2;   // first ray, primitive, env and obstacle id of the lane's primitive
@@ -758,6 +793,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         }
         return h;
     };
+    int pending = 0;  // (general shape) the item this wave has drawn and not yet worked
     {
         const SenseArgs a2 = reload_args();
         const SenseArgs& a = a2;
@@ -791,8 +827,8 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         // when an env's obstacles sit in an aligned power-of-two group of lanes
         // of one wave, its nearest obstacle is a shuffle reduction
         const bool lanes_per_env = O > 0 && (O & (O - 1)) == 0 && TE * O <= 64;
-        for (int task = wave; task < n_tasks; task += n_waves) {
-            for (int i0 = 0; i0 < n_obst || (task == 0 && i0 == 0); i0 += 64) {
+        auto run_job = [&](int task, int i0) {
+            {
                 const int i = i0 + lane;
                 const bool live = i < n_obst;
                 const int el = live ? fast_div(i, inv_O) : 0;
@@ -864,27 +900,23 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                     if (live && o == 0) env_summary(a, e, bd, bd < __builtin_inf() ? bi : -1);
                 } else if (task == 0 && live && o >= C) {
                     // general shape: park the polygon's distance beside the
-                    // circles' for the walk below (no other task reads this slot)
+                    // circles' for the per-env minimum taken after the barrier
+                    // (no other task reads this slot)
                     obst[OB_DIST * ob_n + i] = dist;
                 }
             }
-            if (task == 0 && !lanes_per_env) {
-                // the wave that parked the distances walks them per env
-                for (int el = lane; el < ne; el += 64) {
-                    double bd = __builtin_inf();
-                    int bi = -1;
-                    for (int o = 0; o < O; ++o) {
-                        const double d = obst[OB_DIST * ob_n + el * O + o];
-                        if (d < bd) {
-                            bd = d;
-                            bi = o;
-                        }
-                    }
-                    env_summary(a, e0 + el, bd, bi);
-                }
-            }
+        };
+        if constexpr (FIXED) {
+            for (int task = wave; task < n_tasks; task += n_waves)
+                for (int i0 = 0; i0 < n_obst || (task == 0 && i0 == 0); i0 += 64) run_job(task, i0);
+        } else {
+            // jobs, the wave's own number first, then off the queue; the first item that is not a job is kept
+            // for the sweep below
+            for (pending = wave; pending < n_jobs; pending = draw(0, 0))
+                run_job(pending % n_tasks, (pending / n_tasks) << 6);
         }
     }
+    const bool summary_after_barrier = !(O > 0 && (O & (O - 1)) == 0 && TE * O <= 64);
     AUV_STAMP(4);
     // sweep 0: nearest hit of every ray.  The hits of the first rounds of the
     // wave's first unit stay in registers for sweep 1, which settles the
@@ -894,29 +926,43 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
 #pragma unroll
     for (int j = 0; j < kKeep; ++j) kept[j].clear();
     bool walk_again = false;  // same for the whole wave
-    if (wave >= first_ray_wave) {
-        bool first_unit = true;
-        for (int w = wave - first_ray_wave; w < n_units * n_share; w += n_ray_waves) {
-            const int u = FIXED ? w : w / n_share, part = FIXED ? 0 : w - u * n_share;  // rounds part, part + n_share, ...
-            const Unit U = unit_open(u);
-            int j0 = part * 64;
-            if (first_unit) {
+    bool first_unit = true;
+    // returns: bit 0 = rounds of this part are left for sweep 1 to walk again, bit 1 = its first rounds were kept
+    auto sweep0 = [&](int u, int part) -> int {
+        const Unit U = unit_open(u);
+        int j0 = part * 64;
+        int flags = first_unit ? 2 : 0;
+        if (first_unit) {
 #pragma unroll
-                for (int j = 0; j < kKeep; ++j) {
-                    if (j0 < U.total) {
-                        const PairHit h = unit_pair(U, j0 + lane);
-                        if (h.ok) atomicMin(&best[h.slot], h.key);
-                        kept[j].set(h);
-                    }
-                    j0 += n_share * 64;
+            for (int j = 0; j < kKeep; ++j) {
+                if (j0 < U.total) {
+                    const PairHit h = unit_pair(U, j0 + lane);
+                    if (h.ok) atomicMin(&best[h.slot], h.key);
+                    kept[j].set(h);
                 }
-                first_unit = false;
+                j0 += n_share * 64;
             }
-            for (; j0 < U.total; j0 += n_share * 64) {
-                const PairHit h = unit_pair(U, j0 + lane);
-                if (h.ok) atomicMin(&best[h.slot], h.key);
-                walk_again = true;
-            }
+            first_unit = false;
+        }
+        for (; j0 < U.total; j0 += n_share * 64) {
+            const PairHit h = unit_pair(U, j0 + lane);
+            if (h.ok) atomicMin(&best[h.slot], h.key);
+            walk_again = true;
+            flags |= 1;
+        }
+        return flags;
+    };
+    if constexpr (FIXED) {
+        if (wave >= first_ray_wave)
+            for (int w = wave - first_ray_wave; w < n_units; w += n_ray_waves) sweep0(w, 0);
+    } else {
+        // sweep items off the same counter; what each leaves for sweep 1 is filed per item, for whichever wave
+        // draws it there
+        for (int it = pending; it < n_items; it = draw(0, 0)) {
+            const int w = it - n_jobs;
+            const int u = w / n_share;
+            const int f = sweep0(u, w - u * n_share);  // rounds part, part + n_share, ...
+            if (lane == 0) item_flag[w] = (unsigned char)f;
         }
     }
     AUV_STAMP(5);
@@ -933,20 +979,75 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     const int n_w = a_out.cnn_w ? cnn_n_weights(a_out.cnn_kind) : 0;
     float w_mine = 0.f;
     if (tid < n_w) w_mine = a_out.cnn_w[tid];
+    if (summary_after_barrier) {
+        // General shape: every obstacle's distance is in obst[] now (the circles' from phase 1, the polygons'
+        // parked by the jobs of task 0, possibly on several waves).  The nearest obstacle of an env, lowest id
+        // among equals: a wave per env when there are enough obstacles to share out, else a lane per env.
+        if (O >= 16) {
+            for (int el = wave; el < ne; el += n_waves) {
+                double bd = __builtin_inf();
+                int bi = -1;
+                for (int o = lane; o < O; o += 64) {
+                    const double d = obst[OB_DIST * ob_n + el * O + o];
+                    if (d < bd) {
+                        bd = d;
+                        bi = o;
+                    }
+                }
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const double od = __shfl_xor(bd, d, 64);
+                    const int oi = __shfl_xor(bi, d, 64);
+                    if (od < bd || (od == bd && oi >= 0 && (bi < 0 || oi < bi))) {
+                        bd = od;
+                        bi = oi;
+                    }
+                }
+                if (lane == 0) env_summary(a_out, e0 + el, bd, bi);
+            }
+        } else if (wave == 0) {
+            for (int el = lane; el < ne; el += 64) {
+                double bd = __builtin_inf();
+                int bi = -1;
+                for (int o = 0; o < O; ++o) {
+                    const double d = obst[OB_DIST * ob_n + el * O + o];
+                    if (d < bd) {
+                        bd = d;
+                        bi = o;
+                    }
+                }
+                env_summary(a_out, e0 + el, bd, bi);
+            }
+        }
+        // an attached network's input takes the bytes of obst[] below: not before every wave has read them
+        if (a_out.cnn_w) __syncthreads();
+    }
     // sweep 1
 #pragma unroll
     for (int j = 0; j < kKeep; ++j)
         if (kept[j].ok() && best[kept[j].slot()] == kept[j].key) atomicMin(&ids[kept[j].slot()], kept[j].oid());
-    if (walk_again) {
-        bool first_unit = true;
-        for (int w = wave - first_ray_wave; w < n_units * n_share; w += n_ray_waves) {
-            const int u = FIXED ? w : w / n_share, part = FIXED ? 0 : w - u * n_share;
-            const Unit U = unit_open(u);
-            for (int j0 = (part + (first_unit ? kKeep * n_share : 0)) * 64; j0 < U.total; j0 += n_share * 64) {
-                const PairHit h = unit_pair(U, j0 + lane);
-                if (h.ok && best[h.slot] == h.key) atomicMin(&ids[h.slot], h.oid);
+    auto sweep1 = [&](int u, int part, bool kept_first) {
+        const Unit U = unit_open(u);
+        for (int j0 = (part + (kept_first ? kKeep * n_share : 0)) * 64; j0 < U.total; j0 += n_share * 64) {
+            const PairHit h = unit_pair(U, j0 + lane);
+            if (h.ok && best[h.slot] == h.key) atomicMin(&ids[h.slot], h.oid);
+        }
+    };
+    if constexpr (FIXED) {
+        if (walk_again) {
+            first_unit = true;
+            for (int w = wave - first_ray_wave; w < n_units; w += n_ray_waves) {
+                sweep1(w, 0, first_unit);
+                first_unit = false;
             }
-            first_unit = false;
+        }
+    } else {
+        // every sweep item again, off the second counter, by whichever wave is free: the rounds its first wave
+        // did not keep in registers
+        for (int w = wave; w < n_units * n_share; w = draw(1, 0)) {
+            const int f = item_flag[w];
+            if (!(f & 1)) continue;
+            const int u = w / n_share;
+            sweep1(u, w - u * n_share, (f & 2) != 0);
         }
     }
     for (int f = tid; f < ne * R; f += nthr) {

@@ -400,8 +400,8 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.cnn_kind = h->cnn_kind;
     {
         const SenseLayout L = sense_layout(sa.TE, d.R, d.C, d.P, d.NV, sa.cnn_w ? sa.cnn_kind : -1);
-        const size_t off[10] = {L.env, L.circ, L.seg, L.best, L.obst, L.edist, L.ids, L.ecross, L.live, L.wsum};
-        for (int i = 0; i < 10; ++i) sa.lds[i] = (int)off[i];
+        const size_t off[11] = {L.env, L.circ, L.seg, L.best, L.obst, L.edist, L.ids, L.ecross, L.live, L.wsum, L.queue};
+        for (int i = 0; i < 11; ++i) sa.lds[i] = (int)off[i];
     }
     sa.cnn_head = h->cnn_head;
     const int blocks = (d.V + h->raster_te - 1) / h->raster_te;

@@ -53,4 +53,8 @@ for k in range(9):
     print(f"{names[k]:34s}", np.round(d[:, :, k].mean(axis=0)).astype(int))
 print(f"{'whole kernel per wave':34s}", np.round((t[:, :, 9] - t[:, :, 0]).mean(axis=0)).astype(int))
 span = t[:, :, 9].max(axis=1) - t[:, :, 0].min(axis=1)
-print("workgroup span mean", span.mean(), "launch span", t[:, :, 9].max() - t[:, :, 0].min(), "ticks (100 MHz: 10 ns each)")
+print("workgroup span percentiles 50/90/99/max:", np.percentile(span, [50, 90, 99, 100]).round())
+slow = np.argsort(span)[-max(1, len(span) // 100):]
+print("the slowest 1 % of the workgroups, mean ticks per phase and wave:")
+for k in range(9):
+    print(f"{names[k]:34s}", np.round(d[slow][:, :, k].mean(axis=0)).astype(int))
