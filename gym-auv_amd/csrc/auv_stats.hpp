@@ -1,6 +1,6 @@
 // Episode statistics of a batch, reduced on the device in two launches.
 //
-// k_stats_partial   one workgroup per kStatsEnvs envs: per env the nearest LiDAR
+// k_stats_partial   one workgroup per 16 to kStatsEnvs envs (stats_envs_per_block): per env the nearest LiDAR
 //                   return (min over its rays) and the largest obstacle risk, and
 //                   the sums of the flags and the reward; one record of
 //                   kStatsFields doubles per workgroup into a workspace.
@@ -17,11 +17,12 @@
 namespace auv {
 
 constexpr int kStatsFields = 8;   // env_steps, done, collisions, goals, truncations, reward, min range, max risk
-constexpr int kStatsEnvs = 64;    // envs per workgroup of k_stats_partial
+constexpr int kStatsEnvs = 64;    // envs per workgroup of k_stats_partial, at most
 constexpr int kStatsThreads = 256;
 
 struct StatsArgs {
     int V, R, O;
+    int envs_per_block;  // stats_envs_per_block(V)
     const uint8_t* done;
     const uint8_t* collision;
     const uint8_t* reached_goal;
@@ -48,33 +49,54 @@ __device__ __forceinline__ double wave_max(double v) {
 __global__ __launch_bounds__(kStatsThreads) void k_stats_partial(StatsArgs a) {
     __shared__ double part[kStatsThreads / 64][kStatsFields];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int e0 = blockIdx.x * kStatsEnvs;
+    const int e0 = blockIdx.x * a.envs_per_block;
     double acc[kStatsFields];
 #pragma unroll
     for (int f = 0; f < kStatsFields; ++f) acc[f] = 0.0;
-    // wave w takes envs e0 + w, e0 + w + 4, ...: every lane runs the same trip count
-    for (int k = wave; k < kStatsEnvs; k += kStatsThreads / 64) {
+    // Wave w takes the envs e0 + 4 w .. e0 + 4 w + 3, then 16 further on, up to the workgroup's share.  Four envs
+    // at a time: four independent loads per lane are in flight (the kernel only reads; what it waits for is
+    // memory).  Past the batch's end the last env is read again, without a branch, and left out of the sums.
+    constexpr int kGroup = 4;
+    for (int k = wave * kGroup; k < a.envs_per_block; k += (kStatsThreads / 64) * kGroup) {
         const int e = e0 + k;
         if (e >= a.V) break;  // wave-uniform
-        double lo = __builtin_inf(), hi = 0.0;  // risks are never negative
-        const double* rg = a.ranges + (size_t)e * a.R;
+        const double* rg[kGroup];
+        const double* rk[kGroup];
+        double lo[kGroup], hi[kGroup];
+#pragma unroll
+        for (int g = 0; g < kGroup; ++g) {
+            const int eg = e + g < a.V ? e + g : a.V - 1;
+            rg[g] = a.ranges + (size_t)eg * a.R;
+            rk[g] = a.risk + (size_t)eg * a.O;
+            lo[g] = __builtin_inf();
+            hi[g] = 0.0;  // risks are never negative
+        }
         for (int r = lane; r < a.R; r += 64) {
-            lo = nan_min(lo, rg[r]);
+            double t[kGroup];
+#pragma unroll
+            for (int g = 0; g < kGroup; ++g) t[g] = rg[g][r];
+#pragma unroll
+            for (int g = 0; g < kGroup; ++g) lo[g] = nan_min(lo[g], t[g]);
         }
-        const double* rk = a.risk + (size_t)e * a.O;
         for (int o = lane; o < a.O; o += 64) {
-            hi = nan_max(hi, rk[o]);
+            double t[kGroup];
+#pragma unroll
+            for (int g = 0; g < kGroup; ++g) t[g] = rk[g][o];
+#pragma unroll
+            for (int g = 0; g < kGroup; ++g) hi[g] = nan_max(hi[g], t[g]);
         }
-        lo = wave_min(lo);
-        hi = wave_max(hi);
-        acc[0] = acc[0] + 1.0;
-        acc[1] = acc[1] + (double)a.done[e];
-        acc[2] = acc[2] + (double)a.collision[e];
-        acc[3] = acc[3] + (double)a.reached_goal[e];
-        acc[4] = acc[4] + (double)a.truncated[e];
-        acc[5] = acc[5] + a.reward[e];
-        acc[6] = acc[6] + lo;
-        acc[7] = acc[7] + hi;
+#pragma unroll
+        for (int g = 0; g < kGroup; ++g) {
+            if (e + g >= a.V) break;  // wave-uniform
+            acc[0] = acc[0] + 1.0;
+            acc[1] = acc[1] + (double)a.done[e + g];
+            acc[2] = acc[2] + (double)a.collision[e + g];
+            acc[3] = acc[3] + (double)a.reached_goal[e + g];
+            acc[4] = acc[4] + (double)a.truncated[e + g];
+            acc[5] = acc[5] + a.reward[e + g];
+            acc[6] = acc[6] + wave_min(lo[g]);
+            acc[7] = acc[7] + wave_max(hi[g]);
+        }
     }
     if (lane == 0) {
 #pragma unroll
@@ -116,6 +138,9 @@ __global__ __launch_bounds__(kStatsThreads) void k_stats_final(const double* rec
     }
 }
 
-inline int stats_blocks(int V) { return (V + kStatsEnvs - 1) / kStatsEnvs; }
+// Envs per workgroup: 16 (four waves x four envs in flight) while that keeps the grid under 4,096 workgroups, then
+// 32, then 64: small batches still spread over the device, and a batch of 1,048,576 envs has 16,384 records.
+inline int stats_envs_per_block(int V) { return V <= 16 * 4096 ? 16 : V <= 32 * 4096 ? 32 : kStatsEnvs; }
+inline int stats_blocks(int V) { return (V + stats_envs_per_block(V) - 1) / stats_envs_per_block(V); }
 
 }  // namespace auv

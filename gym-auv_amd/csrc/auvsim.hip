@@ -516,7 +516,10 @@ int launch_stats(auv_sim* h, double* records, double* out, int accumulate, hipSt
     sa.ranges = bp<double>(h, AUV_BUF_RANGES);
     sa.risk = bp<double>(h, AUV_BUF_RISK);
     sa.records = records;
+    sa.envs_per_block = stats_envs_per_block(d.V);
     const int blocks = stats_blocks(d.V);
+    if (blocks > kScratchRecords && d.V <= AUV_STATS_MAX_ENVS)  // the fixed array holds every batch it admits
+        return fail(h, AUV_ERR_STATE, "statistics grid of %d workgroups exceeds %d records", blocks, kScratchRecords);
     hipLaunchKernelGGL(k_stats_partial, dim3(blocks), dim3(kStatsThreads), 0, st, sa);
     HIP_TRY(h, hipGetLastError());
     hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(kStatsThreads), 0, st, records, blocks, out, accumulate);
