@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void k_vessel(VesselArgs a) {
 struct SenseArgs {
     Dims d;
     int TE;       // envs per workgroup
-    int lds[11];  // byte offsets of the LDS arrays (sense_layout, computed once on the host): env, circ, seg,
-                  // best, obst, edist, ids, ecross, live, wsum, queue
+    int lds[10];  // byte offsets of the LDS arrays (sense_layout, computed once on the host): env, circ, seg,
+                  // best, obst, edist, ids, ecross, live, wsum (the queue follows wsum: sense_queue_offset)
     int is_step;  // 1: advance obstacles, finish the reward; 0: after reset / plain sense
     int with_meta;  // 0: bearing, course and risk of the obstacles are not refreshed by this pass
     int refresh_heading;  // 0: the heading_ts column (a constant of the scene) is rewritten only for restarting envs
@@ -223,6 +223,11 @@ __host__ __device__ inline size_t sense_max_items(int TE, int C, int P, int NV) 
     return 2 * (rounds ? rounds : 1) + units * kShareMax;
 }
 
+// the queue's place in the LDS image: right behind wsum[] (one count per block of 64 edges, and one to spare)
+__host__ __device__ inline size_t sense_queue_offset(size_t wsum, int TE, int S) {
+    return wsum + (((size_t)TE * S + 63) / 64 + 1) * 4;
+}
+
 __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P, int NV, int cnn_kind, bool packed = false) {
     SenseLayout L;
     const size_t S = (size_t)P * NV, O = (size_t)C + P;
@@ -241,8 +246,8 @@ __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P,
     L.live = o; o += (size_t)TE * S * (packed ? 1 : 2);
     o = (o + 3) & ~(size_t)3;
     L.wsum = o; o += (((size_t)TE * S + 63) / 64 + 1) * 4;
-    L.queue = o;
-    if (!packed) o += 8 + ((sense_max_items(TE, C, P, NV) + 3) & ~(size_t)3);
+    L.queue = sense_queue_offset(L.wsum, TE, (int)S);
+    if (!packed) o = L.queue + 8 + ((sense_max_items(TE, C, P, NV) + 3) & ~(size_t)3);
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
@@ -272,25 +277,22 @@ struct PairHit {
     unsigned long long key;
 };
 
-// A hit remembered between the two sweeps: three registers when ray slot (< 2^28) and obstacle id (< 16) share a
-// word, as they do in the compile-time shape, else four.
-template <bool PACKED>
+// A hit remembered between the two sweeps, in three registers: the key, and ray slot and obstacle id in one word,
+// ~0 for none.  The id takes the low 4 bits in the compile-time shape (16 obstacles), else the low 12: a tile's LDS
+// image ends below 4,096 obstacles (40 B each) and 2^15 ray slots (12 B each), so the two always fit.
+template <bool FIXED>
 struct KeptHit {
+    static constexpr int kIdBits = FIXED ? 4 : 12;
     unsigned long long key;
-    unsigned int a, b;  // PACKED: a = slot << 4 | oid, ~0 for none;  else a = slot, ~0 for none, b = oid
+    unsigned int a;
     __device__ __forceinline__ void clear() { a = 0xffffffffu; }
     __device__ __forceinline__ void set(const PairHit& h) {
         key = h.key;
-        if (PACKED) {
-            a = h.ok ? ((unsigned int)h.slot << 4) | h.oid : 0xffffffffu;
-        } else {
-            a = h.ok ? (unsigned int)h.slot : 0xffffffffu;
-            b = h.oid;
-        }
+        a = h.ok ? ((unsigned int)h.slot << kIdBits) | h.oid : 0xffffffffu;
     }
     __device__ __forceinline__ bool ok() const { return a != 0xffffffffu; }
-    __device__ __forceinline__ int slot() const { return (int)(PACKED ? a >> 4 : a); }
-    __device__ __forceinline__ unsigned int oid() const { return PACKED ? a & 15u : b; }
+    __device__ __forceinline__ int slot() const { return (int)(a >> kIdBits); }
+    __device__ __forceinline__ unsigned int oid() const { return a & ((1u << kIdBits) - 1u); }
 };
 
 template <bool PACKED>
@@ -410,8 +412,12 @@ __device__ __forceinline__ SenseArgs reload_args() {
     return r;
 }
 
-template <int RISK, bool FIXED>
+// QUEUED (general shape only): the work of the interval between the first two barriers is drawn from a counter in
+// LDS instead of being dealt by wave number (see there); the launcher picks it for tiles whose work is long and
+// uneven.
+template <int RISK, bool FIXED, bool QUEUED = false>
 __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
+    static_assert(!(FIXED && QUEUED), "the compile-time shape is dealt by wave number");
     const SenseArgs& a = a0;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int V = a.d.V;
@@ -419,13 +425,13 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     const int NV = FIXED ? DefaultShape::NV : a.d.NV, O = FIXED ? DefaultShape::C + DefaultShape::P : a.d.O;
     const int S = P * NV;
     const int TE = FIXED ? DefaultShape::TE : a.TE;
-    struct { int env, circ, seg, best, obst, edist, ids, ecross, live, wsum, queue; } L = {
-        a.lds[0], a.lds[1], a.lds[2], a.lds[3], a.lds[4], a.lds[5], a.lds[6], a.lds[7], a.lds[8], a.lds[9], a.lds[10]};
+    struct { int env, circ, seg, best, obst, edist, ids, ecross, live, wsum; } L = {
+        a.lds[0], a.lds[1], a.lds[2], a.lds[3], a.lds[4], a.lds[5], a.lds[6], a.lds[7], a.lds[8], a.lds[9]};
     if (FIXED) {
         // constants but for the room an attached network takes in front of best[]
         const SenseLayout T = sense_layout(TE, R, C, P, NV, a.cnn_w ? a.cnn_kind : -1, true);
         L = {(int)T.env, (int)T.circ, (int)T.seg, (int)T.best, (int)T.obst, (int)T.edist, (int)T.ids, (int)T.ecross,
-             (int)T.live, (int)T.wsum, (int)T.queue};
+             (int)T.live, (int)T.wsum};
     }
     double* env = reinterpret_cast<double*>(lds_raw + L.env);
     double* circ = reinterpret_cast<double*>(lds_raw + L.circ);
@@ -455,8 +461,9 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         return FIXED ? (int)(lds_raw + L.live)[idx] : (int)reinterpret_cast<const unsigned short*>(lds_raw + L.live)[idx];
     };
     int* wsum = reinterpret_cast<int*>(lds_raw + L.wsum);
-    int* queue = reinterpret_cast<int*>(lds_raw + L.queue);                 // (general shape) two counters,
-    unsigned char* item_flag = lds_raw + L.queue + 8;                        // then a byte per work item
+    // (queued tiles) two counters, then a byte per work item
+    int* queue = reinterpret_cast<int*>(lds_raw + (QUEUED ? (int)sense_queue_offset((size_t)L.wsum, TE, S) : 0));
+    unsigned char* item_flag = reinterpret_cast<unsigned char*>(queue) + 8;
     const int e0 = blockIdx.x * TE;
     const int ne = min(TE, V - e0);
     const int n_circ = ne * C;
@@ -485,9 +492,13 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         env_s = er[ER_SIN];
         env_psi = a.state[2 * (size_t)V + e0 + tid];
     }
-    if (!FIXED && tid == 0) {
-        queue[0] = nthr >> 6;  // every wave's first item is its own number: the draws start behind those
-        queue[1] = nthr >> 6;
+    if (QUEUED && tid == 0) {
+        // the first sweep items are dealt by wave number (sweep 0: to the waves without a job; sweep 1: to all):
+        // the draws start behind those
+        // (used by the queued tiles only; their number of job waves as computed below)
+        const int rounds = max(1, (ne * O + 63) >> 6), tasks = a.with_meta ? 2 : 1, nw = nthr >> 6;
+        queue[0] = nw - min(tasks * rounds, max(tasks, (2 * nw) / 3));
+        queue[1] = nw;
     }
     const unsigned long long range_bits = (unsigned long long)__double_as_longlong(range);
     for (int f = tid; f < ne * R; f += nthr) {
@@ -654,10 +665,12 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     //
     // Work items of the interval.  In the compile-time shape the tasks of phase 2
     // have the first waves and the sweep's units the others.  In the general
-    // shape the waves draw items from a counter in LDS as they become free:
-    // first the jobs of phase 2 (task x round of 64 obstacles), then the sweep's
-    // (unit, part) pairs, so that a dense scene's obstacle rounds and a long
-    // unit's rounds spread over the whole workgroup whatever their sizes.
+    // shape the jobs of phase 2 (task x round of 64 obstacles) have the first
+    // waves, as many as the obstacle rounds call for, and the sweep's (unit,
+    // part) pairs are drawn from a counter in LDS by the waves as they become
+    // free, the other waves' first items being their own numbers: a dense
+    // scene's obstacle rounds and a long unit's rounds spread over the whole
+    // workgroup whatever their sizes.
     const int n_tasks = a.with_meta ? 2 : 1;
     const int n_rounds = FIXED ? 1 : max(1, (ne * O + 63) >> 6);
     const int n_jobs = n_tasks * n_rounds;
@@ -665,19 +678,31 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     int n_live = 0;
     for (int b = 0; b < n_blocks; ++b) n_live += wsum[b];
     const int units_c = (n_circ + 63) >> 6, n_units = units_c + ((n_live + 63) >> 6);
+    // Tiles whose work is long and uneven -- three rounds of obstacles or more, or twice the rays a unit's rounds
+    // are sized for (sense_wants_queue) -- take it `queued`: the jobs on two thirds of the waves, the sweep items
+    // drawn from the counter.
+    // The others keep the fixed deal: the two tasks on the first two waves (all the waves, when there are no
+    // more), a task's rounds in turn on its wave, the units' parts round the other waves; what the counter and
+    // its flags cost, and what a sweep item that is not its wave's first costs in sweep 1, outweigh the balance.
+    const int by_rays = (R + 179) / 180;
+    constexpr bool queued = QUEUED;
+    const int n_job_waves = queued ? min(n_jobs, max(n_tasks, (2 * n_waves) / 3)) : (n_waves > n_tasks ? n_tasks : n_waves);
+    const int free_waves = n_waves > n_tasks || queued ? n_waves - n_job_waves : 0;
     // A unit's rounds are dealt into n_share parts, each an item of its own (its wave opens the unit again): more
-    // parts the more rays a primitive can cover, and at least enough for every wave to find one.
-    const int by_rays = (R + 179) / 180, by_waves = n_units > 0 ? n_waves / n_units : 1;
-    const int n_share = (FIXED || n_units == 0) ? 1 : min(kShareMax, max(1, max(by_rays, by_waves)));
-    const int n_items = n_jobs + n_units * n_share;
-    AUV_CHECK(FIXED || n_items <= (int)sense_max_items(TE, C, P, NV));
+    // parts the more rays a primitive can cover, and with waves to spare enough for each to find one.
+    const int by_waves = n_units == 0 ? 1 : free_waves >= 2 * n_units ? free_waves / n_units
+                         : (free_waves == 0 && n_waves >= 2 * n_units) ? n_waves / n_units : 1;
+    const int n_share = (FIXED || n_units == 0) ? 1 : QUEUED ? min(kShareMax, max(by_rays, by_waves)) : by_waves;
+    const int n_sweep = n_units * n_share;
+    AUV_CHECK(!QUEUED || n_jobs + n_sweep <= (int)sense_max_items(TE, C, P, NV));
     // the next item off counter `which`, the same in every lane; items >= n_items: the list has run out
     auto draw = [&](int which, int base) -> int {
         int it = 0;
         if (lane == 0) it = atomicAdd(&queue[which], 1);
         return base + __builtin_amdgcn_readfirstlane(it);
     };
-    const int first_ray_wave = n_tasks, n_ray_waves = n_waves - n_tasks;  // (compile-time shape only)
+    // the fixed deal: the waves that sweep
+    const int first_ray_wave = FIXED ? n_tasks : (n_waves > n_tasks ? n_tasks : 0), n_ray_waves = n_waves - first_ray_wave;
     struct Unit {
         int incl, excl, total;      // running count of pairs up to and with this lane's primitive, without it; all
         unsigned int desc, desc2;   // first ray, primitive, env and obstacle id of the lane's primitive
@@ -708,21 +733,13 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
             }
         } else {
             const int j = ((u - units_c) << 6) + lane;
-            if (j < n_live) {
-                // the j-th listed edge: walk the blocks' counts
-                int b = 0, before = 0;
-                for (int nb = wsum[0]; j >= before + nb; nb = wsum[b]) {
-                    before += nb;
-                    ++b;
-                }
-                AUV_CHECK(b >= 0 && b < n_blocks);
-                const int i = live_get((b << 6) + (j - before));
+            // candidate rays of listed edge i: the arc between the bearings of its two endpoints
+            auto edge_interval = [&](int i) {
                 AUV_CHECK(i >= 0 && i < ne * S);
                 el = fast_div(i, inv_S);
                 oid = C + fast_div(i - el * S, inv_NV);
                 prim = n_circ + i;
                 const double* sg = seg + (size_t)i * (FIXED ? 4 : 5);
-                // candidate rays: the arc between the bearings of the two endpoints
                 const float fax = (float)sg[0], fay = (float)sg[1], fex = (float)sg[2], fey = (float)sg[3];
                 const float fbx = fax + fex, fby = fay + fey;
                 const float dmin = fast_sqrtf((float)edist[i]);
@@ -742,6 +759,36 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                         const float lo = d >= 0.0f ? xa : xa + d;
                         iv = make_interval(lo, lo + fabsf(d), R, margin);
                     }
+                }
+            };
+            if constexpr (!QUEUED) {
+                if (j < n_live) {
+                    // the j-th listed edge: walk the blocks' counts
+                    int b = 0, before = 0;
+                    for (int nb = wsum[0]; j >= before + nb; nb = wsum[b]) {
+                        before += nb;
+                        ++b;
+                    }
+                    AUV_CHECK(b >= 0 && b < n_blocks);
+                    edge_interval(live_get((b << 6) + (j - before)));
+                }
+            } else {
+                // Many blocks: their counts (64 blocks at most: the LDS image ends at 4,096 edges) summed over the
+                // wave once, every lane taking part; a lane then finds its block by bisection instead of walking
+                // the counts one LDS read after the other.
+                AUV_CHECK(n_blocks <= 64);
+                const int blk_cnt = lane < n_blocks ? wsum[lane] : 0;
+                const int blk_incl = wave_inclusive_sum(blk_cnt);
+                int lo4 = 0;  // 4 x the number of blocks whose listed edges all come before the j-th
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const int probe = __builtin_amdgcn_ds_bpermute(lo4 + (step - 1) * 4, blk_incl);
+                    lo4 = probe <= j ? lo4 + step * 4 : lo4;
+                }
+                const int before = __builtin_amdgcn_ds_bpermute(lo4, blk_incl - blk_cnt);
+                if (j < n_live) {
+                    AUV_CHECK((lo4 >> 2) < n_blocks && j - before >= 0 && j - before < 64);
+                    edge_interval(live_get(((lo4 >> 2) << 6) + (j - before)));
                 }
             }
         }
@@ -793,7 +840,6 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         }
         return h;
     };
-    int pending = 0;  // (general shape) the item this wave has drawn and not yet worked
     {
         const SenseArgs a2 = reload_args();
         const SenseArgs& a = a2;
@@ -906,17 +952,32 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                 }
             }
         };
-        if constexpr (FIXED) {
-            for (int task = wave; task < n_tasks; task += n_waves)
+        if constexpr (!QUEUED) {
+            for (int task = wave; task < n_tasks; task += n_waves) {
                 for (int i0 = 0; i0 < n_obst || (task == 0 && i0 == 0); i0 += 64) run_job(task, i0);
+                if (task == 0 && !lanes_per_env) {
+                    // the wave that parked the distances walks them per env
+                    for (int el = lane; el < ne; el += 64) {
+                        double bd = __builtin_inf();
+                        int bi = -1;
+                        for (int o = 0; o < O; ++o) {
+                            const double d = obst[OB_DIST * ob_n + el * O + o];
+                            if (d < bd) {
+                                bd = d;
+                                bi = o;
+                            }
+                        }
+                        env_summary(a, e0 + el, bd, bi);
+                    }
+                }
+            }
         } else {
-            // jobs, the wave's own number first, then off the queue; the first item that is not a job is kept
-            // for the sweep below
-            for (pending = wave; pending < n_jobs; pending = draw(0, 0))
-                run_job(pending % n_tasks, (pending / n_tasks) << 6);
+            for (int job = wave; wave < n_job_waves && job < n_jobs; job += n_job_waves)
+                run_job(job % n_tasks, (job / n_tasks) << 6);
         }
     }
-    const bool summary_after_barrier = !(O > 0 && (O & (O - 1)) == 0 && TE * O <= 64);
+    // (queued tiles: an env's obstacles may be on several waves, its nearest one is found behind the barrier)
+    const bool summary_after_barrier = QUEUED && !(O > 0 && (O & (O - 1)) == 0 && TE * O <= 64);
     AUV_STAMP(4);
     // sweep 0: nearest hit of every ray.  The hits of the first rounds of the
     // wave's first unit stay in registers for sweep 1, which settles the
@@ -926,12 +987,11 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
 #pragma unroll
     for (int j = 0; j < kKeep; ++j) kept[j].clear();
     bool walk_again = false;  // same for the whole wave
-    bool first_unit = true;
     // returns: bit 0 = rounds of this part are left for sweep 1 to walk again, bit 1 = its first rounds were kept
-    auto sweep0 = [&](int u, int part) -> int {
+    auto sweep0 = [&](int u, int part, bool& first_unit) -> int {
         const Unit U = unit_open(u);
         int j0 = part * 64;
-        int flags = first_unit ? 2 : 0;
+        int flags = (QUEUED && first_unit) ? 2 : 0;
         if (first_unit) {
 #pragma unroll
             for (int j = 0; j < kKeep; ++j) {
@@ -947,21 +1007,26 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         for (; j0 < U.total; j0 += n_share * 64) {
             const PairHit h = unit_pair(U, j0 + lane);
             if (h.ok) atomicMin(&best[h.slot], h.key);
-            walk_again = true;
-            flags |= 1;
+            if (QUEUED) flags |= 1;
+            else walk_again = true;
         }
         return flags;
     };
-    if constexpr (FIXED) {
-        if (wave >= first_ray_wave)
-            for (int w = wave - first_ray_wave; w < n_units; w += n_ray_waves) sweep0(w, 0);
+    if constexpr (!QUEUED) {
+        if (wave >= first_ray_wave) {
+            bool first_unit = true;
+            for (int w = wave - first_ray_wave; w < n_units * n_share; w += n_ray_waves) {
+                const int u = FIXED ? w : w / n_share, part = FIXED ? 0 : w - u * n_share;  // rounds part, part + n_share, ...
+                sweep0(u, part, first_unit);
+            }
+        }
     } else {
+        bool first_unit = true;
         // sweep items off the same counter; what each leaves for sweep 1 is filed per item, for whichever wave
         // draws it there
-        for (int it = pending; it < n_items; it = draw(0, 0)) {
-            const int w = it - n_jobs;
+        for (int w = wave >= n_job_waves ? wave - n_job_waves : draw(0, 0); w < n_sweep; w = draw(0, 0)) {
             const int u = w / n_share;
-            const int f = sweep0(u, w - u * n_share);  // rounds part, part + n_share, ...
+            const int f = sweep0(u, w - u * n_share, first_unit);  // rounds part, part + n_share, ...
             if (lane == 0) item_flag[w] = (unsigned char)f;
         }
     }
@@ -983,7 +1048,27 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         // General shape: every obstacle's distance is in obst[] now (the circles' from phase 1, the polygons'
         // parked by the jobs of task 0, possibly on several waves).  The nearest obstacle of an env, lowest id
         // among equals: a wave per env when there are enough obstacles to share out, else a lane per env.
-        if (O >= 16) {
+        if (O < 64) {
+            // a group of lanes per env (the next power of two above its obstacles), several envs per wave
+            int group = 1;
+            while (group < O) group <<= 1;
+            const int per_wave = 64 / group, o = lane & (group - 1);
+            for (int g0 = wave * per_wave; g0 < ne; g0 += n_waves * per_wave) {
+                const int el = g0 + lane / group;
+                const bool have = el < ne && o < O;
+                double bd = have ? obst[OB_DIST * ob_n + (have ? el * O + o : 0)] : __builtin_inf();
+                int bi = bd < __builtin_inf() ? o : -1;
+                for (int d = group >> 1; d >= 1; d >>= 1) {
+                    const double od = __shfl_xor(bd, d, 64);
+                    const int oi = __shfl_xor(bi, d, 64);
+                    if (od < bd || (od == bd && oi >= 0 && (bi < 0 || oi < bi))) {
+                        bd = od;
+                        bi = oi;
+                    }
+                }
+                if (el < ne && o == 0) env_summary(a_out, e0 + el, bd, bi);
+            }
+        } else {
             for (int el = wave; el < ne; el += n_waves) {
                 double bd = __builtin_inf();
                 int bi = -1;
@@ -1004,19 +1089,6 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                 }
                 if (lane == 0) env_summary(a_out, e0 + el, bd, bi);
             }
-        } else if (wave == 0) {
-            for (int el = lane; el < ne; el += 64) {
-                double bd = __builtin_inf();
-                int bi = -1;
-                for (int o = 0; o < O; ++o) {
-                    const double d = obst[OB_DIST * ob_n + el * O + o];
-                    if (d < bd) {
-                        bd = d;
-                        bi = o;
-                    }
-                }
-                env_summary(a_out, e0 + el, bd, bi);
-            }
         }
         // an attached network's input takes the bytes of obst[] below: not before every wave has read them
         if (a_out.cnn_w) __syncthreads();
@@ -1032,18 +1104,19 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
             if (h.ok && best[h.slot] == h.key) atomicMin(&ids[h.slot], h.oid);
         }
     };
-    if constexpr (FIXED) {
+    if constexpr (!QUEUED) {
         if (walk_again) {
-            first_unit = true;
-            for (int w = wave - first_ray_wave; w < n_units; w += n_ray_waves) {
-                sweep1(w, 0, first_unit);
+            bool first_unit = true;
+            for (int w = wave - first_ray_wave; w < n_units * n_share; w += n_ray_waves) {
+                const int u = FIXED ? w : w / n_share, part = FIXED ? 0 : w - u * n_share;
+                sweep1(u, part, first_unit);
                 first_unit = false;
             }
         }
     } else {
         // every sweep item again, off the second counter, by whichever wave is free: the rounds its first wave
         // did not keep in registers
-        for (int w = wave; w < n_units * n_share; w = draw(1, 0)) {
+        for (int w = wave; w < n_sweep; w = draw(1, 0)) {
             const int f = item_flag[w];
             if (!(f & 1)) continue;
             const int u = w / n_share;
@@ -1083,6 +1156,16 @@ template <int RISK>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_sense(SenseArgs a) {
     sense_tile<RISK, false>(a);
 }
+
+// general shape, its work drawn from the queue
+template <int RISK>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_sense_queued(SenseArgs a) {
+    sense_tile<RISK, false, true>(a);
+}
+
+// Which tiles the queue pays for: three rounds of 64 obstacles or more per tile, or rays enough for a unit's rounds
+// to be dealt in parts.
+inline bool sense_wants_queue(int TE, int O, int R) { return (TE * O + 63) / 64 >= 3 || R >= 360; }
 
 // DefaultShape.  A CU admits floor(800 / (scalar registers rounded up to 16, + 16)) workgroups of 256
 // threads, 512 / (vector registers rounded up to 8) waves per SIMD and 160 KiB of LDS: held to 80 scalar

@@ -400,19 +400,22 @@ int launch_fused(auv_sim* h, hipStream_t st, hipEvent_t* ev, int do_step, const 
     sa.cnn_kind = h->cnn_kind;
     {
         const SenseLayout L = sense_layout(sa.TE, d.R, d.C, d.P, d.NV, sa.cnn_w ? sa.cnn_kind : -1);
-        const size_t off[11] = {L.env, L.circ, L.seg, L.best, L.obst, L.edist, L.ids, L.ecross, L.live, L.wsum, L.queue};
-        for (int i = 0; i < 11; ++i) sa.lds[i] = (int)off[i];
+        const size_t off[10] = {L.env, L.circ, L.seg, L.best, L.obst, L.edist, L.ids, L.ecross, L.live, L.wsum};
+        for (int i = 0; i < 10; ++i) sa.lds[i] = (int)off[i];
     }
     sa.cnn_head = h->cnn_head;
     const int blocks = (d.V + h->raster_te - 1) / h->raster_te;
     const bool fixed = is_default_shape(d, h->raster_te, h->sense_block);
     // the compile-time shape has a narrower LDS image
     const size_t lds_fixed = sense_layout(sa.TE, d.R, d.C, d.P, d.NV, sa.cnn_w ? sa.cnn_kind : -1, true).total;
+    const bool queued = !fixed && sense_wants_queue(sa.TE, d.O, d.R);
     if (h->risk_model == AUV_RISK_REFERENCE) {
         if (fixed) hipLaunchKernelGGL(k_sense_default<1>, dim3(blocks), dim3(h->sense_block), lds_fixed, st, sa);
+        else if (queued) hipLaunchKernelGGL(k_sense_queued<1>, dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
         else hipLaunchKernelGGL(k_sense<1>, dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
     } else {
         if (fixed) hipLaunchKernelGGL(k_sense_default<0>, dim3(blocks), dim3(h->sense_block), lds_fixed, st, sa);
+        else if (queued) hipLaunchKernelGGL(k_sense_queued<0>, dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
         else hipLaunchKernelGGL(k_sense<0>, dim3(blocks), dim3(h->sense_block), h->raster_lds, st, sa);
     }
     HIP_TRY(h, hipGetLastError());
@@ -692,6 +695,10 @@ int auv_create(const auv_config* cfg, int device, auv_handle* out) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sense<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsMax) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_sense<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kLdsMax) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_sense_queued<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kLdsMax) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_sense_queued<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsMax) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_lidar), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsMax) != hipSuccess) {

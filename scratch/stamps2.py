@@ -1,6 +1,6 @@
 """Where the waves of k_sense spend their time, any workload: mean shader-clock ticks between the phase stamps of a
 diagnostic build (-DAUV_PHASE_STAMPS), per wave of the workgroup.
-Usage: AUVSIM_LIB=scratch/libauvsim_stamps.so python scratch/stamps2.py WORKLOAD [block]"""
+Usage: AUVSIM_LIB=scratch/libauvsim_stamps.so python scratch/stamps2.py WORKLOAD [block [tile]]"""
 import ctypes
 import os
 import sys
@@ -16,8 +16,10 @@ from gym_auv_amd.sim import AuvSim
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg5_dense_720"
 cfg, scene = scenarios.make_workload(name)
 sim = AuvSim(cfg, device=0)
-if len(sys.argv) > 2:
+if len(sys.argv) > 2 and int(sys.argv[2]):
     sim.set_option(_lib.OPT_SENSE_BLOCK, int(sys.argv[2]))
+if len(sys.argv) > 3:
+    sim.set_option(_lib.OPT_RASTER_TILE, int(sys.argv[3]))
 sim.set_option(_lib.OPT_AUTO_RESET, 1)
 sim.set_scene(scene)
 dev = torch.device("cuda:0")
