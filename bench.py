@@ -148,6 +148,18 @@ def measured_valu_insts(key, kernel):
         return None
 
 
+def measured_counter_ratios(key, kernel):
+    """Ratios of the committed PMC passes that need no clock or cycles-per-instruction assumption: the share of the
+    device's VALU issue cycles the kernel used, the share of wave cycles spent waiting, LDS bank conflicts per
+    LDS-active cycle; {} when the workload has no committed pass."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            e = json.load(f)[key][kernel]
+        return {k: e[k] for k in ("valu_busy", "wait_frac", "lds_conflict_frac") if k in e}
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
 # one VALU instruction per SIMD every 4 cycles (a 64-wide wave on 16 lanes), 4 SIMDs x 256 CUs, 2.4 GHz
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0
 
@@ -584,9 +596,13 @@ def main():
                 out["valu_issue"] = {
                     "kernel": "k_sense", "achieved": vi / sense_s, "peak": VALU_ISSUE_PEAK, "unit": "wave-instr/s",
                     "frac": vi / sense_s / VALU_ISSUE_PEAK, "insts_per_launch": vi,
+                    "from_counters": measured_counter_ratios(tkey, "k_sense"),
                     "note": "executed VALU wave-instructions per launch, from the committed PMC pass over a "
-                            "200-step rollout of this workload (profiles/traffic.json), over THIS run's average launch "
-                            f"time ({args.steps} steps), against the issue rate of 1024 SIMDs at 2.4 GHz"}
+                            "rollout of this workload (profiles/traffic.json), over THIS run's average launch "
+                            f"time ({args.steps} steps), against the issue rate of 1024 SIMDs at 2.4 GHz with 4 cycles "
+                            "per instruction; from_counters.valu_busy is the same share taken from cycle counters "
+                            "alone (SQ_ACTIVE_INST_VALU x 4 over the launch's GRBM_GUI_ACTIVE cycles x 1024 SIMDs): "
+                            "the figure to quote"}
             vb = float(VESSEL_BYTES_PER_ENV) * V
             out["roofline_vessel"] = {
                 "kernel": "k_vessel", "bound": "hbm", "achieved": vb / vessel_s / 1e9, "peak": HBM_PEAK_GBS,
