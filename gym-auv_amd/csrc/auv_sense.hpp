@@ -30,6 +30,11 @@
 
 namespace auv {
 
+typedef unsigned long long auv_u64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int auv_u32x4 __attribute__((ext_vector_type(4)));
+typedef double auv_f64x2 __attribute__((ext_vector_type(2)));
+typedef float auv_f32x4 __attribute__((ext_vector_type(4)));
+
 // per-vessel record handed from k_vessel to k_sense, f64 [V,8]
 enum EnvRec { ER_COS = 0, ER_SIN, ER_VOX, ER_VOY, ER_REWARD, ER_RESET, ER_COUNT = 8 };
 
@@ -236,11 +241,15 @@ __host__ __device__ inline SenseLayout sense_layout(int TE, int R, int C, int P,
     L.circ = o; o += (size_t)TE * C * 4 * 8;
     L.seg = o; o += (size_t)TE * S * (packed ? 4 : 5) * 8;
     const size_t act = cnn_kind < 0 ? 0 : (size_t)TE * cnn_act_floats(cnn_kind) * 4;
-    const size_t xw = cnn_kind < 0 ? 0 : (((size_t)TE * R + cnn_n_weights(cnn_kind)) * 4 + 7) & ~(size_t)7;
+    const size_t xw = cnn_kind < 0 ? 0 : (((size_t)TE * R + cnn_n_weights(cnn_kind)) * 4 + 15) & ~(size_t)15;
     const size_t bb = (size_t)TE * R * 8, ob = ((size_t)TE * O * 5 + (size_t)TE * P * 3) * 8;
+    // best[], ids[] and the network's input (in obst[]) are walked in 16-byte pieces: they start at multiples of 16
+    o = (o + 15) & ~(size_t)15;
     L.best = o; o += bb > act ? bb : act;
+    o = (o + 15) & ~(size_t)15;
     L.obst = o; o += ob > xw ? ob : xw;
     L.edist = o; o += (size_t)TE * S * 8;
+    o = (o + 15) & ~(size_t)15;
     L.ids = o; o += (size_t)TE * R * 4;
     L.ecross = o; o += (size_t)TE * S * (packed ? 1 : 4);
     L.live = o; o += (size_t)TE * S * (packed ? 1 : 2);
@@ -500,10 +509,24 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         queue[0] = nw - min(tasks * rounds, max(tasks, (2 * nw) / 3));
         queue[1] = nw;
     }
+    // The per-ray arrays are walked four rays per lane when the ray count allows (every tile then starts at a
+    // multiple of four rays, in LDS and in memory alike): 16-byte LDS accesses and stores, a quarter of the loop and
+    // address instructions, which are most of what these loops execute.
+    const bool by_four = FIXED || (R & 3) == 0;
     const unsigned long long range_bits = (unsigned long long)__double_as_longlong(range);
-    for (int f = tid; f < ne * R; f += nthr) {
-        best[f] = range_bits;
-        ids[f] = 0xffffffffu;
+    if (by_four) {
+        const auv_u64x2 rb2 = {range_bits, range_bits};
+        const auv_u32x4 none4 = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        for (int q = tid; q < (ne * R) >> 2; q += nthr) {
+            reinterpret_cast<auv_u64x2*>(best)[2 * q] = rb2;
+            reinterpret_cast<auv_u64x2*>(best)[2 * q + 1] = rb2;
+            reinterpret_cast<auv_u32x4*>(ids)[q] = none4;
+        }
+    } else {
+        for (int f = tid; f < ne * R; f += nthr) {
+            best[f] = range_bits;
+            ids[f] = 0xffffffffu;
+        }
     }
     AUV_STAMP(1);
 
@@ -1123,13 +1146,31 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
             sweep1(u, w - u * n_share, (f & 2) != 0);
         }
     }
-    for (int f = tid; f < ne * R; f += nthr) {
-        const double t = __longlong_as_double((long long)best[f]);
-        const size_t out = (size_t)e0 * R + f;
-        const float close = (float)(1.0 - div_by_const(t, range, a_out.inv_range));
-        __builtin_nontemporal_store(t, &a_out.ranges[out]);
-        __builtin_nontemporal_store(close, &a_out.perception[out]);
-        if (a_out.cnn_w) cnn_x[f] = close;
+    if (by_four) {
+        for (int q = tid; q < (ne * R) >> 2; q += nthr) {
+            const auv_u64x2 b01 = reinterpret_cast<const auv_u64x2*>(best)[2 * q];
+            const auv_u64x2 b23 = reinterpret_cast<const auv_u64x2*>(best)[2 * q + 1];
+            const auv_f64x2 t01 = {__longlong_as_double((long long)b01.x), __longlong_as_double((long long)b01.y)};
+            const auv_f64x2 t23 = {__longlong_as_double((long long)b23.x), __longlong_as_double((long long)b23.y)};
+            const auv_f32x4 close = {(float)(1.0 - div_by_const(t01.x, range, a_out.inv_range)),
+                                     (float)(1.0 - div_by_const(t01.y, range, a_out.inv_range)),
+                                     (float)(1.0 - div_by_const(t23.x, range, a_out.inv_range)),
+                                     (float)(1.0 - div_by_const(t23.y, range, a_out.inv_range))};
+            const size_t out = (size_t)e0 * R + 4 * (size_t)q;
+            __builtin_nontemporal_store(t01, reinterpret_cast<auv_f64x2*>(a_out.ranges + out));
+            __builtin_nontemporal_store(t23, reinterpret_cast<auv_f64x2*>(a_out.ranges + out + 2));
+            __builtin_nontemporal_store(close, reinterpret_cast<auv_f32x4*>(a_out.perception + out));
+            if (a_out.cnn_w) reinterpret_cast<auv_f32x4*>(cnn_x)[q] = close;
+        }
+    } else {
+        for (int f = tid; f < ne * R; f += nthr) {
+            const double t = __longlong_as_double((long long)best[f]);
+            const size_t out = (size_t)e0 * R + f;
+            const float close = (float)(1.0 - div_by_const(t, range, a_out.inv_range));
+            __builtin_nontemporal_store(t, &a_out.ranges[out]);
+            __builtin_nontemporal_store(close, &a_out.perception[out]);
+            if (a_out.cnn_w) cnn_x[f] = close;
+        }
     }
     if (a_out.cnn_w) {
         if (tid < n_w) cnn_wl[tid] = w_mine;
@@ -1138,7 +1179,13 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     AUV_STAMP(7);
     __syncthreads();
     AUV_STAMP(8);
-    for (int f = tid; f < ne * R; f += nthr) __builtin_nontemporal_store((int)ids[f], &a_out.hit[(size_t)e0 * R + f]);
+    if (by_four) {
+        for (int q = tid; q < (ne * R) >> 2; q += nthr)
+            __builtin_nontemporal_store(reinterpret_cast<const auv_u32x4*>(ids)[q],
+                                        reinterpret_cast<auv_u32x4*>(a_out.hit + (size_t)e0 * R) + q);
+    } else {
+        for (int f = tid; f < ne * R; f += nthr) __builtin_nontemporal_store((int)ids[f], &a_out.hit[(size_t)e0 * R + f]);
+    }
     if (a_out.cnn_w) {
         // the tile's scans together, output elements dealt over the workgroup;
         // each is summed by one thread in the order k_cnn uses: same values.
