@@ -574,8 +574,10 @@ def main():
             out["roofline_cnn"] = {"kernel": "k_cnn", "bound": "hbm", "achieved": cb / cnn_ms / 1e6,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cb / cnn_ms / 1e6 / HBM_PEAK_GBS,
                                    "traffic": None, "avg_launch_ms": cnn_ms}
-        tkey = f"{args.workload}/{V}/" + (f"{args.cnn}-attached" if cnn_dim else
-                                           f"{args.cnn}-separate" if net is not None else "none")
+        # cfg4 is cfg3's scene family and shape on every rank: the per-launch counters of one GPU apply to it
+        twork = "cfg3_65536_moving" if args.workload == "cfg4_8x65536_moving" else args.workload
+        tkey = f"{twork}/{V}/" + (f"{args.cnn}-attached" if cnn_dim else
+                                  f"{args.cnn}-separate" if net is not None else "none")
         if args.risk_model != "reference":
             tkey += "/" + args.risk_model     # the committed counters are those of the default index
         if fused:

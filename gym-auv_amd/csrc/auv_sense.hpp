@@ -864,12 +864,12 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         return h;
     };
     {
-        const SenseArgs a2 = reload_args();
-        const SenseArgs& a = a2;
+        // The kernel's arguments are re-read where each task uses them (reload_args), a task's own few at a time:
+        // fetched once at the head of the interval they would all stay live across it, most of them spilled.
         const int n_obst = ne * O;
         // signed hull distance less the vessel radius; polygons: nearest edge
         // (sqrt of the smallest squared distance), sign from the crossing parity
-        auto hull_distance = [&](const double* ob, int el, int o) -> double {
+        auto hull_distance = [&](const SenseArgs& a, const double* ob, int el, int o) -> double {
             if (o < C) return ob[OB_DIST * ob_n];
             const int s0 = el * S + (o - C) * NV;
             const int nv = ecross_get(s0) >> 1;
@@ -887,7 +887,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         // the dist column and risk input of the reference's index: centre distance
         // less size less clearance; a ship's size is its beam (body-frame vertices
         // across its heading), a circle's its radius, i.e. the hull distance
-        auto ref_distance = [&](const double* ob, int el, int o, double mx, double my) -> double {
+        auto ref_distance = [&](const SenseArgs& a, const double* ob, int el, int o, double mx, double my) -> double {
             if (o < C) return ob[OB_DIST * ob_n];
             const int nv = ecross_get(el * S + (o - C) * NV) >> 1;
             const double beam = pobs[PB_HEADING * pb_n + (el * P + (o - C))];
@@ -908,12 +908,10 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                     double* ob = obst + i;
                     const double mx = ob[OB_MX * ob_n], my = ob[OB_MY * ob_n], rvx = ob[OB_RVX * ob_n], rvy = ob[OB_RVY * ob_n];
                     const size_t eo = (size_t)e * O + o;
-                    double* m = a.meta + eo * 5;
-                    // RISK == 1: the heading, speed and course columns follow the reference's conventions
-                    const double* ov = o < C ? a.circles + ((size_t)e * C + o) * 5 + 3
-                                             : a.poly_pose + ((size_t)e * P + (o - C)) * 6 + 4;
                     if (task == 0) {
-                        dist = hull_distance(ob, el, o);
+                        const SenseArgs a = reload_args();
+                        double* m = a.meta + eo * 5;
+                        dist = hull_distance(a, ob, el, o);
                         double hd = 0.0;
                         if (o >= C) {
                             const double* pb = pobs + (el * P + (o - C));
@@ -926,7 +924,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                             hd = pb[PB_HEADING * pb_n];
                         }
                         a.obst_dist[eo] = dist;
-                        m[1] = RISK == 1 ? ref_distance(ob, el, o, mx, my) : dist;
+                        m[1] = RISK == 1 ? ref_distance(a, ob, el, o, mx, my) : dist;
                         if (RISK == 0) {
                             m[0] = hd;
                             m[2] = __builtin_sqrt(rvx * rvx + rvy * rvy);
@@ -934,6 +932,11 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                     } else {
                         // task 1: bearing, course, relative speed and risk of the obstacle, on one wave: the
                         // bearing and the reference's relative motion are formed once and shared
+                        const SenseArgs a = reload_args();
+                        double* m = a.meta + eo * 5;
+                        // RISK == 1: the heading, speed and course columns follow the reference's conventions
+                        const double* ov = o < C ? a.circles + ((size_t)e * C + o) * 5 + 3
+                                                 : a.poly_pose + ((size_t)e * P + (o - C)) * 6 + 4;
                         const double psi = a.state[2 * (size_t)V + e];
                         const double bearing = wrap_angle(atan2_det(my, mx) - psi);
                         m[3] = bearing;
@@ -944,12 +947,12 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                             m[4] = rm.still ? (psi > 0.0 ? 0.0 : 0.0 - kPi) : atan2_det(rm.wy, rm.wx);
                             if (a.refresh_heading || er[ER_RESET] != 0.0)
                                 m[0] = (ov[0] == 0.0 && ov[1] == 0.0) ? 0.0 : atan2_det(ov[1], ov[0]);
-                            const double dref = ref_distance(ob, el, o, mx, my);
+                            const double dref = ref_distance(a, ob, el, o, mx, my);
                             a.risk[eo] = cri_sum(risk_reference_s_of(rm, mx, my, dref, dref < __builtin_inf()),
                                                  risk_reference_t(mx, my, ov[0], ov[1], bearing));
                         } else {
                             m[4] = wrap_angle(atan2_det(rvy, rvx) - psi);
-                            a.risk[eo] = risk_index(mx, my, rvx, rvy, rvx * rvx + rvy * rvy, hull_distance(ob, el, o), range,
+                            a.risk[eo] = risk_index(mx, my, rvx, rvy, rvx * rvx + rvy * rvy, hull_distance(a, ob, el, o), range,
                                                     a.inv_range, a.w_d, a.w_c, a.t_c);
                         }
                     }
@@ -966,7 +969,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                             bi = oi;
                         }
                     }
-                    if (live && o == 0) env_summary(a, e, bd, bd < __builtin_inf() ? bi : -1);
+                    if (live && o == 0) env_summary(reload_args(), e, bd, bd < __builtin_inf() ? bi : -1);
                 } else if (task == 0 && live && o >= C) {
                     // general shape: park the polygon's distance beside the
                     // circles' for the per-env minimum taken after the barrier
@@ -990,7 +993,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
                                 bi = o;
                             }
                         }
-                        env_summary(a, e0 + el, bd, bi);
+                        env_summary(reload_args(), e0 + el, bd, bi);
                     }
                 }
             }
