@@ -366,11 +366,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    rollout_stats = auv_dist.EpisodeStats(dev)
+
     def episode_stats():
-        # episode statistics of a rollout: one small all-reduce (RCCL), not per step
-        st = auv_dist.EpisodeStats(dev)
-        st.update_from_sim(sim, stream=stream)
-        return st.reduce()
+        # episode statistics of a rollout: two small launches and one small all-reduce (RCCL), not per step; the
+        # totals stay on the device, the bracket's synchronisation covers them and they are read after the timing
+        rollout_stats.update_from_sim(sim, stream=stream, accumulate=False)
+        return rollout_stats.reduce_on_device()
 
     def rollout():
         for k in range(args.steps):
@@ -421,6 +423,7 @@ def main():
         stats = rollout()
         sync_all()
         times.append(time.perf_counter() - t0)
+    stats = auv_dist.totals_as_dict(stats)
 
     # the two collectives on their own: the statistics all-reduce (which the timed region above contains) and the
     # gather of every rank's last scans on the trainer rank 0; barrier-bracketed like the rollouts, 5 repeats each

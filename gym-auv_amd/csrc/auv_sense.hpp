@@ -1194,9 +1194,20 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         // each is summed by one thread in the order k_cnn uses: same values.
         // The activation buffers take the bytes of best[], read for the last time above.
         float* act = reinterpret_cast<float*>(best);
-        cnn_forward<false, true>(cnn_x, R, act, act + cnn_p_floats(a_out.cnn_kind), cnn_act_floats(a_out.cnn_kind), ne, cnn_wl,
-                                 a_out.cnn_out + (size_t)e0 * cnn_out_dim(a_out.cnn_kind, a_out.cnn_head), a_out.cnn_kind,
-                                 a_out.cnn_head, tid, nthr);
+        if (FIXED && a_out.cnn_kind == CNN_SHALLOW && a_out.cnn_head == HEAD_FEATURES) {
+            // One layer of 12 outputs per scan: the last wave (it has the fewest rays to store above) forms each
+            // output whole, its three sector sums in registers: a third of the instructions of the staged form
+            // (no index arithmetic per sector sum, no second pass) and no further barrier.  Same operations in
+            // the same order as every other evaluation of this layer.  (The compile-time shape only: in the
+            // general kernels the second form costs more in scalar registers than it saves.)
+            if (wave == n_waves - 1)
+                conv_sectors<false, false>(cnn_x, R, act, act + cnn_p_floats(CNN_SHALLOW), cnn_act_floats(CNN_SHALLOW), ne,
+                                           cnn_wl, cnn_wl + 45, 1, lane, 64, a_out.cnn_out + (size_t)e0 * 12);
+        } else {
+            cnn_forward<false, true>(cnn_x, R, act, act + cnn_p_floats(a_out.cnn_kind), cnn_act_floats(a_out.cnn_kind), ne,
+                                     cnn_wl, a_out.cnn_out + (size_t)e0 * cnn_out_dim(a_out.cnn_kind, a_out.cnn_head),
+                                     a_out.cnn_kind, a_out.cnn_head, tid, nthr);
+        }
     }
     AUV_STAMP(9);
 }

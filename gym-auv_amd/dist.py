@@ -52,13 +52,24 @@ class EpisodeStats:
                  risk.amax(dim=-1).sum(dtype=f64) if risk is not None else self.vec.new_zeros(())]
         self.vec += torch.stack(parts)
 
-    def update_from_sim(self, sim, stream=None):
+    def update_from_sim(self, sim, stream=None, accumulate=True):
         """The same accumulation, reduced by the library itself (`auv_episode_stats`:
-        two small launches, nothing allocated) instead of ten torch reductions."""
-        sim.episode_stats(self.vec, accumulate=True, stream=stream)
+        two small launches, nothing allocated) instead of ten torch reductions.
+        accumulate=False starts the sums over with this batch."""
+        sim.episode_stats(self.vec, accumulate=accumulate, stream=stream)
 
     def reduce(self, group=None) -> dict:
         return reduce_episode_stats(self.vec, group)
+
+    def reduce_on_device(self, group=None) -> torch.Tensor:
+        """The node-wide totals as a device tensor, without waiting for them: the
+        all-reduce is queued behind the kernels that formed the sums, and nothing
+        is read back (`totals_as_dict` does that, whenever the caller synchronises)."""
+        return all_reduce(self.vec.clone(), group=group)
+
+
+def totals_as_dict(totals: torch.Tensor) -> dict:
+    return dict(zip(STAT_FIELDS, totals.tolist()))
 
 
 def all_reduce(t: torch.Tensor, op=dist.ReduceOp.SUM, group=None) -> torch.Tensor:

@@ -12,4 +12,9 @@ timeout -k 10 200 python bench.py > gpurun_out/r03/bench_cfg3.json.log 2> gpurun
 timeout -k 10 200 python bench.py --steps 20 --warmup 5 > gpurun_out/r03/bench_cfg3_20steps.json.log 2> gpurun_out/r03/bench_cfg3_20.err
 timeout -k 10 200 python bench.py --workload cfg2_4096_static > gpurun_out/r03/bench_cfg2.json.log 2> gpurun_out/r03/bench_cfg2.err
 timeout -k 10 300 python bench.py --workload cfg5_dense_720 --steps 100 > gpurun_out/r03/bench_cfg5.json.log 2> gpurun_out/r03/bench_cfg5.err
+# the kernel statistics of the bench's own command (its untimed stepping included: several thousand launches at speed)
+export TMPDIR=/tmp
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03/kt_default -- python3 bench.py --no-cpu-baseline > gpurun_out/r03/kt_default.log 2>&1
+cp $(find gpurun_out/r03/kt_default -name "*kernel_stats.csv") gpurun_out/r03/kernel_stats_default_cmd.csv
+rm -rf gpurun_out/r03/kt_default
 tail -c 400 gpurun_out/r03/bench_cfg5.json.log
