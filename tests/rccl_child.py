@@ -35,6 +35,7 @@ def main():
     st.update_from_sim(sim)
     local = st.vec.clone()
     totals = st.reduce()
+    out["on_device_equal"] = D.totals_as_dict(st.reduce_on_device()) == totals
     out["stats_equal"] = bool(torch.equal(torch.tensor([totals[k] for k in D.STAT_FIELDS], dtype=torch.float64), local.cpu()))
     out["env_steps"] = totals["env_steps"]
     t = torch.tensor([1.5, -2.0], dtype=torch.float64, device=dev)

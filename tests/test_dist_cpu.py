@@ -49,6 +49,8 @@ def _worker(rank, world, port, q):
         b, e = D.shard_range(V, rank, world)
         env, stats = _run_shard(dict(cfg, n_envs=e - b), D.shard_scene(scene, rank, world), acts[:, :, b:e])
         totals = stats.reduce()
+        # the totals left in a tensor (read back whenever the caller likes) are the same numbers
+        assert D.totals_as_dict(stats.reduce_on_device()) == totals
         scans = D.gather_scans(torch.from_numpy(env.perception), dst=0)
         if rank == 0:
             q.put((totals, scans.numpy()))

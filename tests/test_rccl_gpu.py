@@ -32,7 +32,7 @@ def test_every_collective_of_the_dist_layer_through_rccl():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["backend"] == "nccl" and out["world"] == 1
-    assert out["stats_equal"] and out["env_steps"] == 512.0
+    assert out["stats_equal"] and out["on_device_equal"] and out["env_steps"] == 512.0
     assert out["all_reduce_max"] == [1.5, -2.0]
     assert out["gather_into_out"] and out["gather_new"] and out["gather_samples"] and out["destroyed"]
 
