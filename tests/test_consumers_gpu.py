@@ -77,8 +77,10 @@ def test_scan_feeds_cnn_zero_copy(gold):
     sim.close()
 
 
-@pytest.mark.parametrize("mode,tile", [(_lib.LIDAR_RASTER, 0), (_lib.LIDAR_RASTER, 4), (_lib.LIDAR_ALL_PAIRS, 0)],
-                         ids=["raster", "raster-tile4", "allpairs"])
+@pytest.mark.parametrize("mode,tile", [(_lib.LIDAR_RASTER, 0), (_lib.LIDAR_RASTER, 4), (_lib.LIDAR_RASTER, 2),
+                                       (_lib.LIDAR_RASTER, 12), (_lib.LIDAR_ALL_PAIRS, 0)],
+                         ids=["raster", "raster-tile4", "raster-tile2-general-kernel", "raster-tile12-queued-kernel",
+                              "allpairs"])
 def test_attached_cnn_equals_separate_kernel(gold, mode, tile):
     """A network attached to the batch is evaluated inside the sensing pass
     (in-kernel on the rasterising path); its output must equal the separate
@@ -90,7 +92,10 @@ def test_attached_cnn_equals_separate_kernel(gold, mode, tile):
     cfg, scene = scenarios.make_workload("cfg3_65536_moving", n_envs=V)
     sim = make_sim(cfg, scene, lidar_mode=mode)
     if tile:
-        sim.set_option(_lib.OPT_RASTER_TILE, tile)   # 4 envs per tile: the kernel's compile-time shape
+        # 4 envs per tile: the kernel's compile-time shape; 2: the general kernel; 12 (192 obstacles, three rounds
+        # of 64): the general kernel with the work queue, where the network's input takes the place of the
+        # obstacle records only after the per-env summary has read them
+        sim.set_option(_lib.OPT_RASTER_TILE, tile)
     st = torch.cuda.current_stream()
     acts = torch.from_numpy(scenarios.random_actions(V, 2, seed=5)).cuda()
     for tag in ("shallow", "deep2", "deep"):
