@@ -17,6 +17,15 @@ The models are torch modules with the reference's layers and state-dict keys
 epochs through the library's fused training kernel (`trainer.DeviceTrainer`)
 when the model is one of the three shipped configurations, with the very
 batches the data loaders would have produced.
+
+The RL side (radarCNN.py) is here under its own names too:
+`LidarCNN_shallow_pretrained`, `LidarCNN_not_so_deep_pretrained`,
+`LidarCNN_deep_pretrained`, `NavigatioNN` and `PerceptionNavigationExtractor`,
+feature extractors in the sense of stable-baselines3 (its `BaseFeaturesExtractor`
+is their base class when that package is importable) with the reference's
+constructors and state-dict keys.  Frozen, on a GPU and in their shipped
+configuration they evaluate through the library's CNN kernel, reading the
+simulation's perception buffer in place.
 """
 from __future__ import annotations
 
@@ -190,6 +199,9 @@ class Trainer:
         return v
 
     def train(self):
+        print("---------")   # the reference's banner (trainer.py:73-75)
+        print("Training")
+        print("---------")
         for e in range(self.epochs):
             if self._dev is not None:
                 losses = self._dev.train_epoch(epoch_order(self.dataloader_train))
@@ -205,11 +217,194 @@ class Trainer:
             self._dev.sync_model()
 
 
+# ----------------------------------------------------------------------------
+# RL-side feature extractors (radarCNN.py:10-280)
+# ----------------------------------------------------------------------------
+try:   # stable-baselines3 is what the reference derives them from (radarCNN.py:7)
+    from stable_baselines3.common.torch_layers import BaseFeaturesExtractor as _ExtractorBase
+except ImportError:
+    class _ExtractorBase(torch.nn.Module):
+        """What BaseFeaturesExtractor gives its subclasses: the observation
+        space and the `features_dim` property."""
+
+        def __init__(self, observation_space, features_dim: int = 0):
+            super().__init__()
+            assert features_dim > 0
+            self._observation_space = observation_space
+            self._features_dim = features_dim
+
+        @property
+        def features_dim(self) -> int:
+            return self._features_dim
+
+
+def _circ_conv(cin, cout, k, stride, pad):
+    return torch.nn.Conv1d(cin, cout, k, stride=stride, padding=pad, padding_mode="circular")
+
+
+class _ScanExtractor(_ExtractorBase):
+    """Common part of the three: `forward` runs the layers of
+    `feature_extractor` (and `linear_1`) in turn, as radarCNN.py:86-94,141-146,
+    177-182 do; a frozen network in its shipped configuration, given a float32
+    CUDA batch of [B,1,180] scans, is evaluated by the library's kernel instead
+    (same values to rounding: tests/test_compat_gpu.py)."""
+
+    _kind = None     # "shallow" | "deep2" | "deep": the library's network of which this is the feature part
+    _shapes = ()     # parameter shapes of the shipped configuration, in state-dict order
+
+    def _layers(self):
+        yield from self.feature_extractor
+        if hasattr(self, "linear_1"):
+            yield from self.linear_1
+
+    def _device_net(self, x):
+        """The library's network for these weights on x's device, or None when
+        the kernel does not apply."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and tuple(x.shape[1:]) == (1, N_SENSORS)):
+            return None
+        params = list(self.parameters())
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            return None   # someone wants gradients: the torch layers
+        if tuple(tuple(p.shape) for p in params) != self._shapes:
+            return None
+        from . import cnn as _cnn
+
+        stamp = (x.device.index,) + tuple((p.data_ptr(), p._version) for p in params)
+        if getattr(self, "_net_stamp", None) != stamp:
+            old = getattr(self, "_net", None)
+            if old is not None:
+                old.close()
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            for k in _cnn.STATE_KEYS[self._kind]:   # the risk head's layers, which the features do not pass through
+                if k not in sd:
+                    n_in = 8 if self._kind == "deep" else 12
+                    sd[k] = torch.zeros((1, n_in) if k.endswith("weight") else (1,))
+            self.__dict__["_net"] = _cnn.LidarCNN(self._kind, sd, device=x.device.index)
+            self.__dict__["_net_stamp"] = stamp
+        return self.__dict__["_net"]
+
+    def __getstate__(self):
+        # copies and pickles of the module are made without the library's handle; the copy makes its own
+        state = dict(self.__dict__)
+        state.pop("_net", None)
+        state.pop("_net_stamp", None)
+        return state
+
+    def forward(self, x):
+        net = self._device_net(x)
+        if net is not None:
+            return net.forward(x.contiguous(), "features")
+        for layer in self._layers():
+            x = layer(x)
+        return x
+
+
+class LidarCNN_deep_pretrained(_ScanExtractor):
+    """radarCNN.py:10-94: four circular convolutions with ReLU and ceil-mode
+    max-pooling, then Linear(72, 40), ReLU, Linear(40, 8)."""
+    _kind = "deep"
+    _shapes = ((2, 1, 9), (2,), (4, 2, 9), (4,), (4, 4, 9), (4,), (6, 4, 9), (6,), (40, 72), (40,), (8, 40), (8,))
+
+    def __init__(self, observation_space, output_channels=(2, 4, 4, 6), kernel_size: int = 9, n_sensors: int = 180,
+                 features_dim: int = 8):
+        super().__init__(observation_space, features_dim=features_dim)
+        self.n_sensors, self.kernel_size = n_sensors, kernel_size
+        self.padding = (kernel_size - 1) // 2
+        self.output_channels = list(output_channels)
+        layers, cin = [], 1
+        for cout in self.output_channels[:4]:
+            layers += [_circ_conv(cin, cout, kernel_size, 1, self.padding), torch.nn.ReLU(),
+                       torch.nn.MaxPool1d(kernel_size=2, stride=2, ceil_mode=True)]
+            cin = cout
+        self.feature_extractor = torch.nn.Sequential(*layers, torch.nn.Flatten())
+        self.linear_1 = torch.nn.Sequential(torch.nn.Linear(12 * self.output_channels[-1], 40), torch.nn.ReLU(),
+                                            torch.nn.Linear(40, 8))
+
+
+class LidarCNN_not_so_deep_pretrained(_ScanExtractor):
+    """radarCNN.py:96-146: Conv1d(1 -> c0, 45, stride 15, circular padding 15),
+    ReLU, two circular 3-tap convolutions (ReLU between), flattened."""
+    _kind = "deep2"
+    _shapes = ((3, 1, 45), (3,), (2, 3, 3), (2,), (1, 2, 3), (1,))
+
+    def __init__(self, observation_space, n_sensors: int = 180, output_channels=(3, 2, 1), kernel_size: int = 45,
+                 features_dim: int = 8):
+        super().__init__(observation_space, features_dim=features_dim)
+        self.n_sensors, self.kernel_size, self.output_channels = n_sensors, kernel_size, list(output_channels)
+        c = self.output_channels
+        self.feature_extractor = torch.nn.Sequential(
+            _circ_conv(1, c[0], 45, 15, 15), torch.nn.ReLU(), _circ_conv(c[0], c[1], 3, 1, 1), torch.nn.ReLU(),
+            _circ_conv(c[1], c[2], 3, 1, 1), torch.nn.Flatten())
+
+
+class LidarCNN_shallow_pretrained(_ScanExtractor):
+    """radarCNN.py:148-182: the one circular convolution, flattened (no ReLU,
+    no linear layer): 12 features."""
+    _kind = "shallow"
+    _shapes = ((1, 1, 45), (1,))
+
+    def __init__(self, observation_space, n_sensors: int = 180, output_channels=(1,), kernel_size: int = 45,
+                 padding: int = 15, stride: int = 15, features_dim: int = 12):
+        super().__init__(observation_space, features_dim=features_dim)
+        self.n_sensors, self.kernel_size, self.padding, self.stride = n_sensors, kernel_size, padding, stride
+        self.output_channels = list(output_channels)
+        self.feature_extractor = torch.nn.Sequential(
+            _circ_conv(1, self.output_channels[0], kernel_size, stride, padding), torch.nn.Flatten())
+
+
+class NavigatioNN(_ExtractorBase):
+    """radarCNN.py:184-193: the navigation features [B,1,n] passed through as [B,n]."""
+
+    def __init__(self, observation_space, features_dim: int = 6):
+        super().__init__(observation_space, features_dim=features_dim)
+        self.passthrough = torch.nn.Identity()
+
+    def forward(self, observations):
+        shape = observations.shape
+        return self.passthrough(observations[:, 0, :].reshape(shape[0], shape[-1]))
+
+
+class PerceptionNavigationExtractor(_ExtractorBase):
+    """radarCNN.py:195-280: per key of the Dict observation space an extractor
+    -- "perception": the shallow network with the weights of `cnn_path` (the
+    keys the file shares with it, radarCNN.py:243-250), frozen; "navigation":
+    the pass-through -- and their outputs concatenated.  `cnn_path` (not a
+    parameter of the reference, which has the path in its body) defaults to the
+    reference's; the file is read without executing anything from it."""
+
+    def __init__(self, observation_space, sensor_dim: int = 180, features_dim: int = 12, kernel_overlap: float = 0.05,
+                 cnn_path: str = "gym_auv/utils/model_shallow_pretrained.json"):
+        super().__init__(observation_space, features_dim=1)   # the real size is known after the loop
+        extractors, total = {}, 0
+        for key, subspace in observation_space.spaces.items():
+            if key == "perception":
+                net = LidarCNN_shallow_pretrained(observation_space=subspace, n_sensors=sensor_dim, output_channels=[1],
+                                                  kernel_size=45, padding=15, stride=15, features_dim=features_dim)
+                have = net.state_dict()
+                pretrained = {k: v for k, v in torch.load(cnn_path, weights_only=True, map_location="cpu").items()
+                              if k in have}
+                print("\nLoading pretrained LidarCNN from", cnn_path)
+                print("Pretraind layers:", [k for k in pretrained.keys()])
+                net.load_state_dict(pretrained)
+                for param in net.parameters():
+                    param.requires_grad = False
+                extractors[key] = net
+                total += features_dim
+            elif key == "navigation":
+                extractors[key] = NavigatioNN(subspace, features_dim=subspace.shape[-1])
+                total += subspace.shape[-1]
+        self.extractors = torch.nn.ModuleDict(extractors)
+        self._features_dim = total
+
+    def forward(self, observations):
+        return torch.cat([extractor(observations[key]) for key, extractor in self.extractors.items()], dim=1)
+
+
 def install_reference_names():
-    """Register `models.lidar_cnn_shallow`, `models.lidar_cnn_deep` and
-    `utils.dataloader` in `sys.modules`, holding the objects above, so that a
-    script written against the reference's layout imports them unchanged
-    (trainer.py:6-7,11).  Refuses to shadow modules of those names that are
+    """Register `models.lidar_cnn_shallow`, `models.lidar_cnn_deep`,
+    `utils.dataloader` and `radarCNN` in `sys.modules`, holding the objects
+    above, so that a script written against the reference's layout imports them
+    unchanged (trainer.py:6-7,11).  Refuses to shadow modules of those names that are
     already imported from somewhere else."""
     def module(name, **objs):
         have = sys.modules.get(name)
@@ -227,6 +422,10 @@ def install_reference_names():
     models.lidar_cnn_deep = module("models.lidar_cnn_deep", LidarCNN_deep=LidarCNN_deep, LidarCNN_2_deep=LidarCNN_2_deep)
     utils = module("utils")
     utils.__path__ = []
+    module("radarCNN", LidarCNN_deep_pretrained=LidarCNN_deep_pretrained,
+           LidarCNN_not_so_deep_pretrained=LidarCNN_not_so_deep_pretrained,
+           LidarCNN_shallow_pretrained=LidarCNN_shallow_pretrained, NavigatioNN=NavigatioNN,
+           PerceptionNavigationExtractor=PerceptionNavigationExtractor)
     utils.dataloader = module("utils.dataloader", load_LiDARDataset=load_LiDARDataset, LiDARDataset=LiDARDataset,
                               calculate_total_risk=calculate_total_risk, N_SENSORS=N_SENSORS,
                               prev_timesteps_feature_enginering=prev_timesteps_feature_enginering)

@@ -132,3 +132,67 @@ def test_reference_import_lines_work_after_install(files):
         for m in [m for m in sys.modules if m == "models" or m.startswith("models.") or m == "utils" or m.startswith("utils.")]:
             if getattr(sys.modules[m], "__gym_auv_amd_compat__", False):
                 del sys.modules[m]
+
+
+# ---- the RL side, radarCNN.py:10-280 ----
+def _golden_state(tag):
+    gold = np.load(os.path.join(G, "cnn_golden.npz"))
+    pre = f"w_{tag}/"
+    return gold, {k[len(pre):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith(pre)}
+
+
+@pytest.mark.parametrize("tag,cls,kw", [
+    ("shallow", "LidarCNN_shallow_pretrained", dict(n_sensors=180, output_channels=[1], kernel_size=45, padding=15,
+                                                    stride=15, features_dim=12)),
+    ("deep2", "LidarCNN_not_so_deep_pretrained", dict(n_sensors=180, output_channels=[3, 2, 1], kernel_size=45,
+                                                      features_dim=12)),
+    ("deep", "LidarCNN_deep_pretrained", dict(n_sensors=180, output_channels=[2, 4, 4, 6], kernel_size=9,
+                                              features_dim=8))])
+def test_pretrained_extractors_take_the_shipped_weights_and_give_the_references_features(tag, cls, kw):
+    """Constructed with the arguments radarCNN.py:219-239 passes, loaded the way radarCNN.py:243-250 loads (the
+    keys the shipped file shares with the extractor, strictly), they return what the reference's own modules
+    returned for the fixture's scans (tests/golden/make_cnn_golden.py)."""
+    from gym_auv_amd.env import Box
+
+    gold, shipped = _golden_state(tag)
+    net = getattr(compat, cls)(observation_space=Box(0.0, 1.0, (1, 180)), **kw)
+    have = net.state_dict()
+    pretrained = {k: v for k, v in shipped.items() if k in have}
+    assert set(pretrained) == set(have) and len(pretrained) < len(shipped)   # the risk head's layers stay behind
+    net.load_state_dict(pretrained)
+    assert net.features_dim == kw["features_dim"]
+    with torch.no_grad():
+        got = net(torch.from_numpy(gold["x"])).numpy()
+    assert got.shape == gold[f"{tag}_features"].shape
+    assert np.abs(got - gold[f"{tag}_features"]).max() <= 1e-6
+
+
+def test_perception_navigation_extractor_as_the_policy_builds_it(tmp_path, capsys):
+    """radarCNN.py:202-280 with the env's Dict observation space: 12 frozen
+    CNN features + the 6 navigation features."""
+    import copy
+
+    from gym_auv_amd.env import Box, DictSpace
+
+    gold, shipped = _golden_state("shallow")
+    path = str(tmp_path / "model_shallow_pretrained.json")
+    torch.save(shipped, path)                     # a torch archive under a .json name, as the reference ships it
+    space = DictSpace({"perception": Box(0.0, 1.0, (1, 180)), "navigation": Box(-np.inf, np.inf, (1, 6))})
+    ext = compat.PerceptionNavigationExtractor(space, sensor_dim=180, features_dim=12, cnn_path=path)
+    assert "Pretraind layers: ['feature_extractor.0.weight', 'feature_extractor.0.bias']" in capsys.readouterr().out
+    assert ext.features_dim == 18 and not any(p.requires_grad for p in ext.parameters())
+    nav = torch.arange(24 * 6, dtype=torch.float32).reshape(24, 1, 6)
+    out = ext({"perception": torch.from_numpy(gold["x"]), "navigation": nav})
+    assert out.shape == (24, 18)
+    assert np.abs(out[:, :12].numpy() - gold["shallow_features"]).max() <= 1e-6
+    assert torch.equal(out[:, 12:], nav[:, 0, :])
+    twin = copy.deepcopy(ext)                     # policies are copied and pickled
+    assert torch.equal(twin({"perception": torch.from_numpy(gold["x"]), "navigation": nav}), out)
+    with pytest.raises(FileNotFoundError):
+        compat.PerceptionNavigationExtractor(space)   # the reference's relative path, absent here
+
+
+def test_radarcnn_import_line_works_after_install():
+    compat.install_reference_names()
+    from radarCNN import PerceptionNavigationExtractor, LidarCNN_shallow_pretrained   # noqa: F401  (radarCNN.py)
+    assert PerceptionNavigationExtractor is compat.PerceptionNavigationExtractor
