@@ -36,6 +36,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# device memory is shared between the ranks' processes through dmabuf handles (what this pool's driver supports);
+# set before anything loads the HIP runtime, inherited by the ranks this script starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X spec: half the 157.3 TF fp32 vector rate
 HBM_PEAK_GBS = 8000.0
