@@ -21,9 +21,10 @@ repeated `--repeats` times; `value` and `ms_per_step` are the median repeat,
 every repeat being the maximum over ranks.
 
 The timed region carries no instrumentation.  The per-kernel durations behind
-`roofline` come from a second pass of the same K steps, in the same process,
-with HIP events recorded around every kernel on the launch stream (that pass is
-slower by the cost of the events and is reported as ms_per_step_with_events).
+`roofline` come from a second pass of the same steps (max(K, 200) of them), in
+the same process, with HIP events recorded around every kernel on the launch
+stream (that pass is slower by the cost of the events and is reported as
+ms_per_step_with_events).
 """
 from __future__ import annotations
 
@@ -471,12 +472,18 @@ def main():
                         "time less the bracket's own, against the trainer's 7 inbound xGMI links x 153 GB/s"}
             del gathered
 
-    # second pass, instrumented: HIP events around every kernel, on the launch stream
+    # second pass, instrumented: HIP events around every kernel, on the launch stream; 200 steps at least, so that
+    # a short run's per-kernel averages are taken over as many launches as a long run's
+    ev_steps = max(args.steps, 200)
     prepare()
     sim.profile(True)
     sim.profile_read()
     t0 = time.perf_counter()
-    rollout()
+    for k in range(ev_steps):
+        sim.step_device(ptrs[k % n_act], stream=stream)
+        if net is not None:
+            net.forward(per_t, "features", out=feats)
+    episode_stats()
     sync_all()
     ev_elapsed = time.perf_counter() - t0
     prof_ms, prof_steps = sim.profile_read()
@@ -548,7 +555,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "repeats": args.repeats, "ms_per_step_all": [x / args.steps * 1e3 for x in t.tolist()],
-            "ms_per_step_with_events": ev_elapsed / args.steps * 1e3,
+            "ms_per_step_with_events": ev_elapsed / ev_steps * 1e3, "steps_with_events": ev_steps,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "vessels_per_gpu": V, "rays": R, "circles": C,
@@ -607,7 +614,7 @@ def main():
                     "from_counters": measured_counter_ratios(tkey, "k_sense"),
                     "note": "executed VALU wave-instructions per launch, from the committed PMC pass over a "
                             "rollout of this workload (profiles/traffic.json), over THIS run's average launch "
-                            f"time ({args.steps} steps), against the issue rate of 1024 SIMDs at 2.4 GHz with 4 cycles "
+                            f"time ({ev_steps} steps), against the issue rate of 1024 SIMDs at 2.4 GHz with 4 cycles "
                             "per instruction; from_counters.valu_busy is the same share taken from cycle counters "
                             "alone (SQ_ACTIVE_INST_VALU x 4 over the launch's GRBM_GUI_ACTIVE cycles x 1024 SIMDs): "
                             "the figure to quote"}
