@@ -457,6 +457,8 @@ SHAPES = [
     (31, 360, 0, 9, 8, 6, 2, 512),
     (33, 720, 40, 40, 8, 8, 2, 1024),   # sixteen waves per workgroup (dense tiles take this size by default)
     (1000, 64, 1, 1, 3, 3, 64, 64),
+    (9, 361, 3, 2, 4, 4, 0, 0),          # the work queue (360 rays and more) with a ray count that is not a multiple of four
+    (21, 90, 70, 30, 3, 3, 2, 256),      # the work queue through four rounds of obstacles, 100 obstacles per env, 90 rays
     (1027, 180, 8, 8, 5, 5, 4, 256),   # the shape with a compile-time instantiation of the sensing kernel; last tile short
 ]
 
