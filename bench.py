@@ -569,6 +569,7 @@ def main():
                        "auto_reset": "finished episodes restart inside the next step, on the device" if auto_reset
                                      else "off",
                        "sharding": f"envs x{world}, no data-path collective"},
+            "sense_launch": sim.launch_info() if fused else None,
             "kernel_ms": ({"k_vessel": vessel_s * 1e3, "k_sense": sense_s * 1e3} if fused else
                           {"k_dynamics": vessel_s * 1e3, "k_encounter": enc_s * 1e3, "k_lidar": sense_s * 1e3}),
             "episode_stats": stats,

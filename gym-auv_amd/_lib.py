@@ -59,6 +59,7 @@ EXPORTS = (
     "auv_cnn_forward", "auv_cnn_last_error", "auv_format_rows", "auv_format_rows_device", "auv_dataset_rows",
     "auv_profile_read", "auv_attach_cnn", "auv_generate_scene", "auv_host_alloc", "auv_host_free",
     "auv_risk_rows", "auv_episode_stats", "auv_episode_stats_static", "auv_train_shallow", "auv_train_cnn", "auv_set_path",
+    "auv_launch_info",
 )
 
 
@@ -147,6 +148,8 @@ def load():
     lib.auv_profile_enable.argtypes = [vp, i32]
     lib.auv_profile_read.restype = C.c_int
     lib.auv_profile_read.argtypes = [vp, dp, C.POINTER(i64)]
+    lib.auv_launch_info.restype = C.c_int
+    lib.auv_launch_info.argtypes = [vp, C.POINTER(i32)]
     lib.auv_format_rows.restype = i64
     lib.auv_format_rows.argtypes = [vp, vp, i64, i64, vp, i64]
     lib.auv_dataset_rows.restype = C.c_int

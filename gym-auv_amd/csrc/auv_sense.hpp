@@ -372,13 +372,25 @@ __device__ __forceinline__ void env_summary(const SenseArgs& a, int e, double bd
 // at the phase boundaries of k_sense; the product build compiles these away.
 #ifdef AUV_PHASE_STAMPS
 __device__ long long* g_stamps = nullptr;
+#if AUV_PHASE_STAMPS == 2   // only the two device-wide stamps: the kernel's registers and timing stay what they are
+#define AUV_STAMP(n)
+#else
 #define AUV_STAMP(n)                                                                                  \
     do {                                                                                              \
         if (g_stamps && (threadIdx.x & 63) == 0)                                                      \
             g_stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (n)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+#endif
+// the device-wide 100 MHz counter (the shader clocks of different CUs cannot be compared with one another): slots
+// 14 and 15 of a wave's record, at the first and the last stamp
+#define AUV_STAMP_REAL(n)                                                                             \
+    do {                                                                                              \
+        if (g_stamps && (threadIdx.x & 63) == 0)                                                      \
+            g_stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (n)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
 #define AUV_STAMP(n)
+#define AUV_STAMP_REAL(n)
 #endif
 
 // Debug builds (-DAUV_DEBUG_BOUNDS) count every violated index bound of the
@@ -491,6 +503,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
     const float inv_NV = __builtin_amdgcn_rcpf((float)NV), inv_O = __builtin_amdgcn_rcpf((float)(O > 0 ? O : 1));
 
     AUV_STAMP(0);
+    AUV_STAMP_REAL(14);
     // ---- phase 0: accumulators (first read after the barrier that ends phase 1)
     // heading (and its sin/cos) of the tile's vessels: requested now, filed at the
     // end of phase 1, so that the first barrier does not wait for global memory
@@ -1210,6 +1223,7 @@ __device__ __forceinline__ void sense_tile(const SenseArgs& a0) {
         }
     }
     AUV_STAMP(9);
+    AUV_STAMP_REAL(15);
 }
 
 // generic shape

@@ -1200,6 +1200,29 @@ int auv_debug_violations(int64_t* out) {
 }
 #endif
 
+int auv_launch_info(auv_handle h, int32_t* out) {
+    if (!h || !out) return AUV_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const Dims& d = h->d;
+    // the same choice of kernel and LDS size as the launch in sense_pass
+    const bool cnn_inside = h->cnn_w && cnn_fits_sense_kernel(h->cnn_kind);
+    const bool fixed = is_default_shape(d, h->raster_te, h->sense_block);
+    const bool queued = !fixed && sense_wants_queue(h->raster_te, d.O, d.R);
+    const size_t lds = fixed ? sense_layout(h->raster_te, d.R, d.C, d.P, d.NV, cnn_inside ? h->cnn_kind : -1, true).total
+                             : h->raster_lds;
+    const bool ref = h->risk_model == AUV_RISK_REFERENCE;
+    const void* fn = fixed ? (ref ? reinterpret_cast<const void*>(k_sense_default<1>) : reinterpret_cast<const void*>(k_sense_default<0>))
+                     : queued ? (ref ? reinterpret_cast<const void*>(k_sense_queued<1>) : reinterpret_cast<const void*>(k_sense_queued<0>))
+                              : (ref ? reinterpret_cast<const void*>(k_sense<1>) : reinterpret_cast<const void*>(k_sense<0>));
+    int per_cu = 0;
+    if (lds <= kLdsMax) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, h->sense_block, lds));
+    out[0] = h->raster_te;
+    out[1] = h->sense_block;
+    out[2] = (int32_t)lds;
+    out[3] = per_cu;
+    return AUV_OK;
+}
+
 #ifdef AUV_PHASE_STAMPS
 // diagnostic builds only: the launch shape of the sensing kernel {envs per workgroup, threads, LDS bytes, 0}
 int auv_debug_geometry(auv_handle h, int32_t* out) {

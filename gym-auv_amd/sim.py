@@ -272,6 +272,12 @@ class AuvSim:
                                                 _stream_handle(stream)))
         return out
 
+    def launch_info(self) -> dict:
+        """How the sensing kernel of this batch is launched (`auv_launch_info`)."""
+        out = (C.c_int32 * 4)()
+        self._check(self._lib.auv_launch_info(self._h, out))
+        return {"envs_per_workgroup": out[0], "threads": out[1], "lds_bytes": out[2], "workgroups_per_cu": out[3]}
+
     # -- profiling ----------------------------------------------------------
     def profile(self, on: bool):
         self._check(self._lib.auv_profile_enable(self._h, 1 if on else 0))

@@ -288,6 +288,12 @@ int auv_set_option(auv_handle h, int32_t key, int32_t value);
 int auv_profile_enable(auv_handle h, int32_t on);
 int auv_profile_read(auv_handle h, double ms[3], int64_t* n_steps);
 
+/* (no counterpart in the reference) How the sensing kernel of this batch is launched on the rasterising path, as it
+ * stands (scene shape, options, attached network): out = {envs per workgroup, threads per workgroup, LDS bytes per
+ * workgroup, workgroups of it that one compute unit holds at a time (the runtime's occupancy figure for that
+ * kernel, block size and LDS size)}.  For benchmarks and tuning: launches nothing. */
+int auv_launch_info(auv_handle h, int32_t out[4]);
+
 /* ---- episode statistics, reduced on the device ------------------------------
  * out (DEVICE f64 [AUV_STATS_FIELDS]) = over the batch's current outputs:
  * {number of envs, sum of AUV_BUF_DONE, of AUV_BUF_COLLISION, of
